@@ -1,0 +1,130 @@
+/*
+ * include/spmv_hip.h -- optional control / introspection / device-resident
+ * API of libhip-spmv.so.  Plain C-ABI: pointers, sizes and ints only.
+ *
+ * None of these is needed by the reference's callers (they only bind the two
+ * symbols of spmv_harness.h); they exist for measurement (bench.py, the
+ * drivers under lilac-benchmarks_amd/host), for the parity tests, and for the
+ * row-partitioned multi-GPU path.  Where a function takes over a job that the
+ * reference GPU backend does implicitly, the reference lines are cited.
+ */
+#ifndef SPMV_HIP_H
+#define SPMV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- kernel / plan identifiers -------------------------------------------- */
+enum {
+    SPMV_HIP_PLAN_AUTO = 0,    /* adaptive: chosen per matrix from its row-length profile   */
+    SPMV_HIP_PLAN_ORDERED = 1, /* one lane per row, sequential, no FMA: bit-identical to     */
+                               /* libspmv/native-impl.c:1-25                                */
+    SPMV_HIP_PLAN_STREAM = 2,  /* row-segment kernel: coalesced a/colidx -> products in LDS  */
+    SPMV_HIP_PLAN_VECTOR = 3,  /* L lanes per row straight from global (L = plan_param)      */
+    SPMV_HIP_PLAN_BINNED = 4   /* rows binned by length, one VECTOR launch per bin           */
+};
+
+/* Opaque device-resident matrix (CSR block + execution plan) on one GPU. */
+typedef struct spmv_hip_matrix spmv_hip_matrix;
+
+typedef struct spmv_hip_info {
+    int32_t rows;        /* rows held by this object (row_end - row_begin)                   */
+    int32_t cols;        /* inferred max(colidx)  (libspmv/gpu.c:217-223 does this on host)  */
+    int64_t nnz;         /* nonzeros held                                                    */
+    int32_t elem_size;   /* 8 = double, 4 = float                                            */
+    int32_t device;      /* HIP device ordinal                                               */
+    int32_t plan;        /* SPMV_HIP_PLAN_* actually in use                                  */
+    int32_t plan_param;  /* lanes per row for VECTOR; nnz per workgroup for STREAM           */
+    int32_t min_row_len, max_row_len;
+    double mean_row_len;
+    int32_t n_blocks;    /* STREAM: row blocks                                               */
+    int32_t n_long_rows; /* rows routed to the long-row kernels                              */
+    int32_t n_launches;  /* kernel launches per SpMV                                         */
+    int32_t reserved;
+    int64_t algorithmic_bytes; /* nnz*(elem+4) + (rows+1)*4 + cols*elem + rows*elem */
+    int64_t device_bytes;      /* HBM actually allocated for this matrix                     */
+} spmv_hip_info;
+
+/* Call-level accounting of the ABI path (spmv_harness_ / f_spmv_harness_). */
+typedef struct spmv_hip_stats {
+    int64_t calls;          /* ABI calls served                                             */
+    int64_t uploads;        /* matrix uploads (cache misses; libspmv/gpu.c:236-262)          */
+    int64_t invalidations;  /* cached copies dropped because the host arrays were written    */
+    double t_init;          /* s: lazy one-time device init                                  */
+    double t_upload;        /* s: matrix H2D + analysis + plan                               */
+    double t_x_h2d;         /* s: per-call x upload        (libspmv/gpu.c:264)               */
+    double t_kernel;        /* s: per-call kernel(s), host-observed                          */
+    double t_y_d2h;         /* s: per-call y download      (libspmv/gpu.c:285)               */
+    double t_total;         /* s: entry -> return, all calls                                 */
+} spmv_hip_stats;
+
+/* ---- runtime ------------------------------------------------------------- */
+int spmv_hip_device_count(void);            /* visible GPUs; 0 when there is none (no abort)  */
+const char *spmv_hip_version(void);
+const char *spmv_hip_last_error(void);      /* message of the last failed int-returning call  */
+
+/* ---- device-resident matrices --------------------------------------------- */
+/*
+ * Uploads rows [row_begin,row_end) of a host CSR matrix (1-based rowstr and
+ * colidx, exactly as handed to spmv_harness_) to `device` and plans its
+ * execution.  elem_size 8 = double, 4 = float.  cols_hint <= 0 infers
+ * max(colidx) over the WHOLE matrix (not just the block) so that partitions
+ * agree on the length of x.  Returns NULL on failure (see spmv_hip_last_error).
+ * Replaces libspmv/gpu.c:66-85 (allocation) and :236-240 (upload).
+ */
+spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const int *colidx, int rows,
+                                        int elem_size, int device, int row_begin, int row_end,
+                                        int cols_hint);
+void spmv_hip_matrix_destroy(spmv_hip_matrix *m);
+int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out);
+/* Force a plan (tests, benchmarks).  plan_param: lanes for VECTOR (1,2,4,..,64), 0 = default. */
+int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param);
+
+/*
+ * y_dev[0..rows) = A * x_dev, both DEVICE pointers on the matrix's device,
+ * enqueued on `stream` (a hipStream_t; NULL = the library's own stream for
+ * that device).  Asynchronous.  Replaces libspmv/gpu.c:270-282.
+ */
+int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream);
+/*
+ * Times `reps` back-to-back SpMVs with HIP events recorded on the stream the
+ * kernels are launched on; *ms_total receives the elapsed milliseconds.
+ */
+int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int reps, void *stream,
+                         float *ms_total);
+
+/* ---- row partition for multi-GPU (pure host arithmetic, no GPU needed) ----- */
+/*
+ * Splits rows into `parts` contiguous blocks of about equal nnz.
+ * bounds[0] = 0 <= bounds[1] <= ... <= bounds[parts] = rows.
+ */
+void spmv_hip_partition_rows(const int *rowstr, int rows, int parts, int *bounds);
+
+/* ---- thin device-memory helpers (so ctypes/C drivers need no HIP headers) --- */
+void *spmv_hip_malloc(int device, size_t bytes);
+void spmv_hip_free(int device, void *p);
+int spmv_hip_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+int spmv_hip_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
+int spmv_hip_memset(int device, void *dst_dev, int value, size_t bytes);
+int spmv_hip_synchronize(int device);
+
+/* Experiment switches for the kernels: key 0 = XCD-contiguous block order (default 1),
+ * key 1 = non-temporal loads of a/colidx (default 0).  Not a stable interface. */
+void spmv_hip_set_tuning(int key, int value);
+
+/* ---- ABI-path control ------------------------------------------------------ */
+void spmv_hip_get_stats(spmv_hip_stats *out);
+void spmv_hip_reset_stats(void);
+/* Drops every cached device copy and disarms write detection (also runs at exit / dlclose). */
+void spmv_hip_release(void);
+/* Info of the matrix most recently used through the ABI (0 on success, -1 if none). */
+int spmv_hip_abi_matrix_info(spmv_hip_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

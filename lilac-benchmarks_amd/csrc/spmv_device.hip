@@ -1,0 +1,571 @@
+/*
+ * csrc/spmv_device.hip -- the thin HIP layer under the C host library.
+ *
+ * Owns everything that touches the HIP runtime: per-device streams, the
+ * device-resident CSR block (spmv_hip_matrix), plan materialisation and kernel
+ * dispatch, event timing, and the small copy helpers the C side
+ * (spmv_harness.c) and the ctypes/C drivers use.  It takes over what the
+ * reference GPU backend does in /root/reference/libspmv/gpu.c:36-86 (setup,
+ * allocation), :217-223 (column-count inference), :236-240 (upload) and
+ * :270-282 (the csrmv call).
+ *
+ * Layout in HBM, per matrix block (rows r0..r1 of the caller's CSR):
+ *   rowptr  int32[rows+1]            0-based, local to the block
+ *   colidx  int32[nnz + PAD]         1-based column ids as the ABI delivers them; pad = 1
+ *   val     T[nnz + PAD]             pad = 0
+ *   plan    int32 row-block / segment / bin lists (O(rows / 8) ints)
+ * x and y are whatever device buffers the caller passes.  Everything is
+ * allocated once per cached matrix; nothing is allocated per SpMV.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <mutex>
+
+#include "spmv_internal.h"
+
+extern "C" void spmvk_set_tuning(int key, int value);
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+#define SPMV_MAX_DEVICES 16
+struct DevCtx {
+    bool ready = false;
+    hipStream_t stream = nullptr;
+};
+DevCtx g_dev[SPMV_MAX_DEVICES];
+std::mutex g_dev_mu;
+
+#define HIPCHK(expr, onfail)                                                                   \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            spmv_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
+                           __LINE__);                                                          \
+            onfail;                                                                            \
+        }                                                                                      \
+    } while (0)
+
+int use_device(int device)
+{
+    if (device < 0 || device >= SPMV_MAX_DEVICES) {
+        spmv_set_error("device ordinal %d out of range", device);
+        return -1;
+    }
+    HIPCHK(hipSetDevice(device), return -1);
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (!g_dev[device].ready) {
+        HIPCHK(hipStreamCreateWithFlags(&g_dev[device].stream, hipStreamNonBlocking), return -1);
+        g_dev[device].ready = true;
+    }
+    return 0;
+}
+
+hipStream_t stream_of(int device, void *stream)
+{
+    return stream ? (hipStream_t)stream : g_dev[device].stream;
+}
+
+} // namespace
+
+struct spmv_hip_matrix {
+    int device = 0;
+    int elem = 8;
+    int rows = 0;
+    int cols = 0;
+    int64_t nnz = 0;
+    int *d_rowptr = nullptr;
+    int *d_col = nullptr;
+    void *d_val = nullptr;
+    size_t device_bytes = 0;
+
+    spmv_row_stats st{};
+    int plan = SPMV_HIP_PLAN_STREAM;
+    int param = SPMV_STREAM_CAP;
+
+    /* STREAM + long rows */
+    spmv_stream_plan sp{};
+    int *d_blk = nullptr;
+    int *d_seg = nullptr;
+    int *d_lrow = nullptr;
+    void *d_partials = nullptr;
+    /* BINNED (built on demand; needs the host rowstr only at creation, so kept as a copy of lens) */
+    spmv_bin_plan bp{};
+    bool have_bins = false;
+    int *d_binrows = nullptr;
+    int *h_rowstr_local = nullptr; /* rows+1 ints, 1-based copy of the block's rowstr (for replans) */
+};
+
+extern "C" {
+
+void spmv_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+const char *spmv_hip_last_error(void) { return g_err; }
+
+const char *spmv_hip_version(void) { return "hip-spmv 0.1 (gfx950)"; }
+
+double spmv_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int spmv_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+/* ---- memory helpers ------------------------------------------------------------- */
+void *spmv_hip_malloc(int device, size_t bytes)
+{
+    if (use_device(device))
+        return nullptr;
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes ? bytes : 16), return nullptr);
+    return p;
+}
+
+void spmv_hip_free(int device, void *p)
+{
+    if (!p)
+        return;
+    if (hipSetDevice(device) == hipSuccess)
+        (void)hipFree(p);
+}
+
+int spmv_hip_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (use_device(device))
+        return -1;
+    /* ordered on the library's stream, then drained: the stream is non-blocking,
+     * so a NULL-stream hipMemcpy would not be ordered against our kernels (the
+     * hazard SURVEY.md 5.2(a) points out in libspmv/gpu.c:41,264,285) */
+    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, g_dev[device].stream),
+           return -1);
+    HIPCHK(hipStreamSynchronize(g_dev[device].stream), return -1);
+    return 0;
+}
+
+int spmv_hip_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (use_device(device))
+        return -1;
+    HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, g_dev[device].stream),
+           return -1);
+    HIPCHK(hipStreamSynchronize(g_dev[device].stream), return -1);
+    return 0;
+}
+
+int spmv_hip_memset(int device, void *dst_dev, int value, size_t bytes)
+{
+    if (use_device(device))
+        return -1;
+    HIPCHK(hipMemsetAsync(dst_dev, value, bytes, g_dev[device].stream), return -1);
+    HIPCHK(hipStreamSynchronize(g_dev[device].stream), return -1);
+    return 0;
+}
+
+int spmv_hip_synchronize(int device)
+{
+    if (use_device(device))
+        return -1;
+    HIPCHK(hipStreamSynchronize(g_dev[device].stream), return -1);
+    HIPCHK(hipDeviceSynchronize(), return -1);
+    return 0;
+}
+
+/* ---- internal helpers for the C host side (spmv_harness.c) ------------------------ */
+void *spmvd_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    HIPCHK(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), return nullptr);
+    return p;
+}
+
+void spmvd_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
+int spmvd_host_register(void *p, size_t bytes)
+{
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault), return -1);
+    return 0;
+}
+
+void spmvd_host_unregister(void *p) { (void)hipHostUnregister(p); }
+
+int spmvd_copy_h2d_async(int device, void *dst_dev, const void *src, size_t bytes)
+{
+    if (use_device(device))
+        return -1;
+    HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, g_dev[device].stream), return -1);
+    return 0;
+}
+
+int spmvd_copy_d2h_async(int device, void *dst, const void *src_dev, size_t bytes)
+{
+    if (use_device(device))
+        return -1;
+    HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, g_dev[device].stream), return -1);
+    return 0;
+}
+
+int spmvd_stream_sync(int device)
+{
+    if (use_device(device))
+        return -1;
+    HIPCHK(hipStreamSynchronize(g_dev[device].stream), return -1);
+    return 0;
+}
+
+/* ---- matrices ------------------------------------------------------------------- */
+
+static void free_plans(spmv_hip_matrix *m)
+{
+    if (m->d_blk)
+        (void)hipFree(m->d_blk);
+    if (m->d_seg)
+        (void)hipFree(m->d_seg);
+    if (m->d_lrow)
+        (void)hipFree(m->d_lrow);
+    if (m->d_partials)
+        (void)hipFree(m->d_partials);
+    if (m->d_binrows)
+        (void)hipFree(m->d_binrows);
+    m->d_blk = m->d_seg = m->d_lrow = m->d_binrows = nullptr;
+    m->d_partials = nullptr;
+    spmv_plan_stream_free(&m->sp);
+    if (m->have_bins)
+        spmv_plan_bins_free(&m->bp);
+    m->have_bins = false;
+}
+
+void spmv_hip_matrix_destroy(spmv_hip_matrix *m)
+{
+    if (!m)
+        return;
+    if (hipSetDevice(m->device) == hipSuccess) {
+        if (g_dev[m->device].ready)
+            (void)hipStreamSynchronize(g_dev[m->device].stream);
+        free_plans(m);
+        if (m->d_rowptr)
+            (void)hipFree(m->d_rowptr);
+        if (m->d_col)
+            (void)hipFree(m->d_col);
+        if (m->d_val)
+            (void)hipFree(m->d_val);
+    }
+    free(m->h_rowstr_local);
+    delete m;
+}
+
+static int upload_ints(int **dst, const int *src, size_t n, size_t *acct)
+{
+    *dst = nullptr;
+    HIPCHK(hipMalloc((void **)dst, (n ? n : 4) * sizeof(int)), return -1);
+    if (n)
+        HIPCHK(hipMemcpy(*dst, src, n * sizeof(int), hipMemcpyHostToDevice), return -1);
+    *acct += (n ? n : 4) * sizeof(int);
+    return 0;
+}
+
+static int ensure_bins(spmv_hip_matrix *m)
+{
+    if (m->have_bins)
+        return 0;
+    if (spmv_plan_bins_build(m->h_rowstr_local, 0, m->rows, SPMV_STREAM_CAP - 4, &m->bp)) {
+        spmv_set_error("out of host memory building row bins");
+        return -1;
+    }
+    m->have_bins = true;
+    if (upload_ints(&m->d_binrows, m->bp.bin_rows, (size_t)m->bp.bin_off[SPMV_NBINS], &m->device_bytes))
+        return -1;
+    return 0;
+}
+
+spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const int *colidx, int rows,
+                                        int elem_size, int device, int row_begin, int row_end,
+                                        int cols_hint)
+{
+    if (elem_size != 8 && elem_size != 4) {
+        spmv_set_error("elem_size must be 8 or 4, got %d", elem_size);
+        return nullptr;
+    }
+    if (row_begin < 0 || row_end > rows || row_begin > row_end) {
+        spmv_set_error("bad row range [%d,%d) of %d rows", row_begin, row_end, rows);
+        return nullptr;
+    }
+    if (use_device(device))
+        return nullptr;
+    hipStream_t st = g_dev[device].stream;
+
+    spmv_hip_matrix *m = new spmv_hip_matrix();
+    m->device = device;
+    m->elem = elem_size;
+    m->rows = row_end - row_begin;
+    const int64_t first = (int64_t)rowstr[row_begin] - 1; /* 0-based offset into a / colidx */
+    m->nnz = (int64_t)rowstr[row_end] - (int64_t)rowstr[row_begin];
+    const size_t n_alloc = (size_t)m->nnz + SPMV_PAD_ELEMS;
+
+#define FAIL()                         \
+    do {                               \
+        spmv_hip_matrix_destroy(m);    \
+        return nullptr;                \
+    } while (0)
+
+    HIPCHK(hipMalloc((void **)&m->d_rowptr, ((size_t)m->rows + 1) * sizeof(int)), FAIL());
+    HIPCHK(hipMalloc((void **)&m->d_col, n_alloc * sizeof(int)), FAIL());
+    HIPCHK(hipMalloc(&m->d_val, n_alloc * (size_t)elem_size), FAIL());
+    m->device_bytes = ((size_t)m->rows + 1) * sizeof(int) + n_alloc * (sizeof(int) + (size_t)elem_size);
+
+    HIPCHK(hipMemcpyAsync(m->d_rowptr, rowstr + row_begin, ((size_t)m->rows + 1) * sizeof(int),
+                          hipMemcpyHostToDevice, st),
+           FAIL());
+    if (m->nnz > 0) {
+        HIPCHK(hipMemcpyAsync(m->d_col, colidx + first, (size_t)m->nnz * sizeof(int),
+                              hipMemcpyHostToDevice, st),
+               FAIL());
+        HIPCHK(hipMemcpyAsync(m->d_val, (const char *)a + first * elem_size, (size_t)m->nnz * elem_size,
+                              hipMemcpyHostToDevice, st),
+               FAIL());
+    }
+    /* padding: colidx = 1 (a valid column), a = 0 */
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(m->d_col + m->nnz), 1, SPMV_PAD_ELEMS, st), FAIL());
+    HIPCHK(hipMemsetAsync((char *)m->d_val + (size_t)m->nnz * elem_size, 0,
+                          (size_t)SPMV_PAD_ELEMS * elem_size, st),
+           FAIL());
+    if (spmvk_rebase(m->d_rowptr, m->rows + 1, rowstr[row_begin], st)) {
+        spmv_set_error("rebase kernel launch failed");
+        FAIL();
+    }
+
+    /* number of columns = max(colidx) over the whole matrix (libspmv/gpu.c:217-223) */
+    if (cols_hint > 0) {
+        m->cols = cols_hint;
+    } else if (row_begin == 0 && row_end == rows) {
+        int *d_max = nullptr;
+        HIPCHK(hipMalloc((void **)&d_max, sizeof(int)), FAIL());
+        HIPCHK(hipMemsetAsync(d_max, 0, sizeof(int), st), FAIL());
+        int rc = spmvk_colmax(m->d_col, m->nnz, d_max, st);
+        int h_max = 0;
+        hipError_t e1 = hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, st);
+        hipError_t e2 = hipStreamSynchronize(st);
+        (void)hipFree(d_max);
+        if (rc || e1 != hipSuccess || e2 != hipSuccess) {
+            spmv_set_error("column-count reduction failed");
+            FAIL();
+        }
+        m->cols = h_max;
+    } else {
+        const int64_t all = (int64_t)rowstr[rows] - rowstr[0];
+        const int *c = colidx + (rowstr[0] - 1);
+        int mx = 0;
+        for (int64_t j = 0; j < all; ++j)
+            mx = c[j] > mx ? c[j] : mx;
+        m->cols = mx;
+    }
+
+    /* host-side planning from the caller's rowstr */
+    m->h_rowstr_local = (int *)malloc(((size_t)m->rows + 1) * sizeof(int));
+    if (!m->h_rowstr_local) {
+        spmv_set_error("out of host memory");
+        FAIL();
+    }
+    memcpy(m->h_rowstr_local, rowstr + row_begin, ((size_t)m->rows + 1) * sizeof(int));
+    spmv_plan_row_stats(m->h_rowstr_local, 0, m->rows, &m->st);
+    if (spmv_plan_stream_build(m->h_rowstr_local, 0, m->rows, SPMV_STREAM_CAP - 4, SPMV_STREAM_ROWCAP,
+                               SPMV_LONG_SEG, &m->sp)) {
+        spmv_set_error("out of host memory building the row-block plan");
+        FAIL();
+    }
+    if (upload_ints(&m->d_blk, m->sp.blk, 2 * ((size_t)m->sp.nblk + 1), &m->device_bytes))
+        FAIL();
+    if (m->sp.nseg > 0) {
+        if (upload_ints(&m->d_seg, m->sp.seg, 4 * (size_t)m->sp.nseg, &m->device_bytes))
+            FAIL();
+        if (upload_ints(&m->d_lrow, m->sp.lrow, 3 * (size_t)m->sp.nlrow, &m->device_bytes))
+            FAIL();
+        HIPCHK(hipMalloc(&m->d_partials, ((size_t)m->sp.nslots + 1) * (size_t)elem_size), FAIL());
+        m->device_bytes += ((size_t)m->sp.nslots + 1) * (size_t)elem_size;
+    }
+    HIPCHK(hipStreamSynchronize(st), FAIL());
+
+    spmv_plan_choose(&m->st, elem_size, &m->plan, &m->param);
+    if (m->plan == SPMV_HIP_PLAN_BINNED && ensure_bins(m))
+        FAIL();
+#undef FAIL
+    return m;
+}
+
+int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
+{
+    if (!m)
+        return -1;
+    if (hipSetDevice(m->device) != hipSuccess)
+        return -1;
+    switch (plan) {
+    case SPMV_HIP_PLAN_AUTO: spmv_plan_choose(&m->st, m->elem, &m->plan, &m->param); break;
+    case SPMV_HIP_PLAN_ORDERED:
+        m->plan = plan;
+        m->param = 1;
+        break;
+    case SPMV_HIP_PLAN_STREAM:
+        m->plan = plan;
+        m->param = SPMV_STREAM_CAP;
+        break;
+    case SPMV_HIP_PLAN_VECTOR: {
+        int l = plan_param > 0 ? plan_param : 64;
+        if (l > 64 || (l & (l - 1))) {
+            spmv_set_error("VECTOR lanes must be a power of two <= 64, got %d", l);
+            return -1;
+        }
+        m->plan = plan;
+        m->param = l;
+        break;
+    }
+    case SPMV_HIP_PLAN_BINNED:
+        m->plan = plan;
+        m->param = 0;
+        break;
+    default: spmv_set_error("unknown plan %d", plan); return -1;
+    }
+    if (m->plan == SPMV_HIP_PLAN_BINNED && ensure_bins(m))
+        return -1;
+    return 0;
+}
+
+static int n_launches(const spmv_hip_matrix *m)
+{
+    int longk = m->sp.nseg > 0 ? 1 + (m->sp.nlrow > 0) : 0;
+    switch (m->plan) {
+    case SPMV_HIP_PLAN_STREAM: return 1 + longk;
+    case SPMV_HIP_PLAN_BINNED: {
+        int n = longk;
+        for (int b = 0; b < SPMV_NBINS; ++b)
+            n += m->bp.bin_off[b + 1] > m->bp.bin_off[b];
+        return n;
+    }
+    default: return 1;
+    }
+}
+
+int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
+{
+    if (!m || !out)
+        return -1;
+    memset(out, 0, sizeof *out);
+    out->rows = m->rows;
+    out->cols = m->cols;
+    out->nnz = m->nnz;
+    out->elem_size = m->elem;
+    out->device = m->device;
+    out->plan = m->plan;
+    out->plan_param = m->param;
+    out->min_row_len = m->rows ? m->st.min_len : 0;
+    out->max_row_len = m->st.max_len;
+    out->mean_row_len = m->st.mean_len;
+    out->n_blocks = m->sp.nblk;
+    out->n_long_rows = m->sp.n_long_rows;
+    out->n_launches = n_launches(m);
+    out->algorithmic_bytes = m->nnz * (int64_t)(m->elem + 4) + ((int64_t)m->rows + 1) * 4 +
+                             (int64_t)m->cols * m->elem + (int64_t)m->rows * m->elem;
+    out->device_bytes = (int64_t)m->device_bytes;
+    return 0;
+}
+
+int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream)
+{
+    if (!m)
+        return -1;
+    if (m->rows == 0)
+        return 0;
+    HIPCHK(hipSetDevice(m->device), return -1);
+    hipStream_t st = stream_of(m->device, stream);
+    spmv_dev_csr d;
+    d.rowptr = m->d_rowptr;
+    d.colidx = m->d_col;
+    d.val = m->d_val;
+    d.rows = m->rows;
+    d.nnz = m->nnz;
+    d.elem_size = m->elem;
+    int rc = 0;
+    switch (m->plan) {
+    case SPMV_HIP_PLAN_ORDERED: rc = spmvk_ordered(&d, x_dev, y_dev, st); break;
+    case SPMV_HIP_PLAN_VECTOR: rc = spmvk_vector(&d, m->param, nullptr, m->rows, x_dev, y_dev, st); break;
+    case SPMV_HIP_PLAN_BINNED:
+        for (int b = 0; b < SPMV_NBINS && !rc; ++b) {
+            int n = m->bp.bin_off[b + 1] - m->bp.bin_off[b];
+            if (n > 0)
+                rc = spmvk_vector(&d, spmv_plan_bin_lanes(b), m->d_binrows + m->bp.bin_off[b], n, x_dev,
+                                  y_dev, st);
+        }
+        if (!rc && m->sp.nseg > 0)
+            rc = spmvk_long(&d, m->d_seg, m->sp.nseg, m->d_lrow, m->sp.nlrow, m->d_partials, x_dev,
+                            y_dev, st);
+        break;
+    case SPMV_HIP_PLAN_STREAM:
+    default:
+        rc = spmvk_stream(&d, m->d_blk, m->sp.nblk, x_dev, y_dev, st);
+        if (!rc && m->sp.nseg > 0)
+            rc = spmvk_long(&d, m->d_seg, m->sp.nseg, m->d_lrow, m->sp.nlrow, m->d_partials, x_dev,
+                            y_dev, st);
+        break;
+    }
+    if (rc) {
+        spmv_set_error("kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return -1;
+    }
+    return 0;
+}
+
+int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int reps, void *stream,
+                         float *ms_total)
+{
+    if (!m || reps <= 0 || !ms_total)
+        return -1;
+    HIPCHK(hipSetDevice(m->device), return -1);
+    hipStream_t st = stream_of(m->device, stream);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0), return -1);
+    HIPCHK(hipEventCreate(&e1), return -1);
+    int rc = 0;
+    HIPCHK(hipEventRecord(e0, st), rc = -1);
+    for (int i = 0; i < reps && !rc; ++i)
+        rc = spmv_hip_spmv_device(m, x_dev, y_dev, st);
+    if (!rc) {
+        HIPCHK(hipEventRecord(e1, st), rc = -1);
+    }
+    if (!rc) {
+        HIPCHK(hipEventSynchronize(e1), rc = -1);
+    }
+    if (!rc) {
+        HIPCHK(hipEventElapsedTime(ms_total, e0, e1), rc = -1);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+void spmv_hip_set_tuning(int key, int value) { spmvk_set_tuning(key, value); }
+
+} // extern "C"

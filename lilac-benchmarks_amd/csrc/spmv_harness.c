@@ -1,0 +1,701 @@
+/*
+ * csrc/spmv_harness.c -- the C host side of libhip-spmv.so: the two ABI
+ * symbols and the policy around them.  Plain C; every HIP call lives behind
+ * the thin layer in spmv_device.hip.
+ *
+ * Mirrors the operator interface of the reference backends, same names, same
+ * argument meaning, same error behaviour:
+ *
+ *   spmv_harness_    /root/reference/libspmv/native.c:3-6   (gpu.c:211-289)
+ *   f_spmv_harness_  /root/reference/libspmv/native.c:8-11  (gpu.c:291-369)
+ *
+ * What the reference GPU backend does and where this file does it differently:
+ *
+ *   device-copy cache keyed on the host pointers (gpu.c:227-234)
+ *       -> kept, but several matrices can be cached at once (SPMV_HIP_CACHE_SLOTS)
+ *          and double/float copies are independent (gpu.c shares d_csrRowPtrA /
+ *          d_csrColIndA between setup() and f_setup(), gpu.c:26-27,122-123).
+ *   write detection by mprotect + SIGSEGV (gpu.c:162-209,245-261)
+ *       -> kept as the default policy, with the defect of SURVEY.md 5.2(d)
+ *          removed: only pages that lie ENTIRELY inside a matrix array are
+ *          protected; the partial first/last page of each array (which Fortran
+ *          COMMON blocks share with the CG vectors, NPB3.3.1/CG/cg.f:69-80) is
+ *          instead compared byte-for-byte against a saved copy on every call.
+ *          A write to a neighbour variable therefore never faults and never
+ *          disarms detection.
+ *       -> SPMV_HIP_CACHE=pointer reproduces gpu-unsafe.c:86-127 (pointer
+ *          equality only), SPMV_HIP_CACHE=off reproduces gpu-slow.c:155-163
+ *          (upload on every call).
+ *   x H2D / csrmv / y D2H on every call (gpu.c:264-285)
+ *       -> same traffic, but ordered on ONE stream (gpu.c:41 vs :264,285 races,
+ *          SURVEY.md 5.2(a)), through pinned staging buffers.
+ *   errors: assert -> abort (gpu.c:42-58)
+ *       -> message on stderr + abort().  There is no CPU fallback: without a
+ *          GPU the first call aborts.
+ *
+ * Environment (read once, at the first call):
+ *   SPMV_HIP_CACHE   = mprotect (default) | pointer | off
+ *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned
+ *   SPMV_HIP_DEVICES = number of GPUs to row-partition over (default 1; "all")
+ *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
+ *                      than devices wraps around -- lets the multi-GPU code path
+ *                      run on one GPU
+ *   SPMV_HIP_PIN     = staging (default) | register | pageable
+ *   SPMV_HIP_STATS   = 1: summary on stderr at exit; 2: also synchronise
+ *                      between the phases of every call to attribute time
+ *   SPMV_HIP_VERBOSE = 1: log uploads / invalidations
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <pthread.h>
+#include <signal.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include "spmv_harness.h"
+#include "spmv_internal.h"
+
+#define MAX_SLOTS 8
+#define MAX_PARTS 16
+#define MAX_REG 32
+
+enum { CACHE_MPROTECT = 0, CACHE_POINTER = 1, CACHE_OFF = 2 };
+enum { PIN_STAGING = 0, PIN_REGISTER = 1, PIN_PAGEABLE = 2 };
+
+/* one guarded host array: [p, p+bytes) */
+typedef struct guard {
+    const char *p;
+    size_t bytes;
+    char *lo, *hi;           /* protected interior pages [lo,hi), lo==hi when none     */
+    size_t head_n, tail_n;   /* bytes of the partial first / last page                  */
+    unsigned char *head, *tail; /* saved copies of those bytes                            */
+} guard;
+
+typedef struct slot {
+    int used;
+    int elem;
+    const void *a;
+    const int *rowstr;
+    const int *colidx;
+    int rows;
+    int first;               /* rowstr[0] at upload time                                */
+    int64_t nnz;
+    int cols;
+    int nparts;
+    int bounds[MAX_PARTS + 1];
+    spmv_hip_matrix *part[MAX_PARTS];
+    int part_dev[MAX_PARTS];
+    void *dx[MAX_PARTS];     /* device x per part (cols elements)                       */
+    void *dy[MAX_PARTS];     /* device y per part (rows of the part)                    */
+    guard g[3];
+    volatile sig_atomic_t armed;
+    volatile sig_atomic_t dirty;
+    uint64_t last_use;
+} slot;
+
+static struct {
+    int inited;
+    int cache, pin, stats, verbose;
+    int plan, plan_param;
+    int ndev, nparts, nslots;
+    long page;
+    slot slots[MAX_SLOTS];
+    uint64_t tick;
+    slot *last;
+    /* pinned staging */
+    void *xstage, *ystage;
+    size_t xstage_n, ystage_n;
+    /* registered caller ranges (SPMV_HIP_PIN=register) */
+    struct {
+        char *lo, *hi;
+    } reg[MAX_REG];
+    int nreg;
+    /* SIGSEGV chaining */
+    int handler_installed;
+    struct sigaction old_sa;
+    spmv_hip_stats st;
+} G;
+
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void die(const char *fmt, ...)
+{
+    va_list ap;
+    fprintf(stderr, "libhip-spmv: fatal: ");
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "\n");
+    abort(); /* the reference's convention: assert() -> abort(), libspmv/gpu.c:42-58 */
+}
+
+#define CHECK(call)                                                        \
+    do {                                                                   \
+        if ((call) != 0)                                                   \
+            die("%s: %s", #call, spmv_hip_last_error());                   \
+    } while (0)
+
+/* ---------------------------------------------------------------- write detection */
+
+static void guard_unprotect(guard *g)
+{
+    if (g->hi > g->lo)
+        mprotect(g->lo, (size_t)(g->hi - g->lo), PROT_READ | PROT_WRITE);
+}
+
+/* async-signal-safe: only mprotect and stores to sig_atomic_t */
+static void on_segv(int sig, siginfo_t *si, void *ctx)
+{
+    char *addr = (char *)si->si_addr;
+    for (int s = 0; s < MAX_SLOTS; ++s) {
+        slot *sl = &G.slots[s];
+        if (!sl->armed)
+            continue;
+        for (int k = 0; k < 3; ++k) {
+            if (addr >= sl->g[k].lo && addr < sl->g[k].hi) {
+                /* the caller is editing a cached matrix: let the write through
+                 * and drop the device copy at the next call (gpu.c:162-183) */
+                sl->dirty = 1;
+                sl->armed = 0;
+                for (int j = 0; j < 3; ++j)
+                    guard_unprotect(&sl->g[j]);
+                return;
+            }
+        }
+    }
+    /* not ours: chain (gpu.c:180-182) */
+    if (G.old_sa.sa_flags & SA_SIGINFO) {
+        if (G.old_sa.sa_sigaction) {
+            G.old_sa.sa_sigaction(sig, si, ctx);
+            return;
+        }
+    } else if (G.old_sa.sa_handler != SIG_DFL && G.old_sa.sa_handler != SIG_IGN) {
+        G.old_sa.sa_handler(sig);
+        return;
+    }
+    /* default action: re-raise with the default disposition */
+    signal(SIGSEGV, SIG_DFL);
+}
+
+static void install_handler(void)
+{
+    if (G.handler_installed)
+        return;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_flags = SA_SIGINFO;
+    sigemptyset(&sa.sa_mask);
+    sa.sa_sigaction = on_segv;
+    if (sigaction(SIGSEGV, &sa, &G.old_sa) == 0)
+        G.handler_installed = 1;
+}
+
+static void guard_free(guard *g)
+{
+    free(g->head);
+    free(g->tail);
+    memset(g, 0, sizeof *g);
+}
+
+/* Splits [p,p+bytes) into protected interior pages and saved partial pages. */
+static int guard_arm(guard *g, const void *p, size_t bytes, int protect)
+{
+    memset(g, 0, sizeof *g);
+    g->p = (const char *)p;
+    g->bytes = bytes;
+    if (bytes == 0)
+        return 0;
+    const uintptr_t pg = (uintptr_t)G.page;
+    uintptr_t b = (uintptr_t)p, e = b + bytes;
+    uintptr_t lo = (b + pg - 1) / pg * pg; /* first page boundary >= b */
+    uintptr_t hi = e / pg * pg;            /* last page boundary  <= e */
+    if (!protect || hi <= lo) {
+        /* no whole page inside: the array is covered by saved copies only */
+        lo = hi = e;
+        if (!protect) { /* pointer policy: nothing saved, nothing protected */
+            g->lo = g->hi = (char *)e;
+            return 0;
+        }
+        g->head_n = bytes;
+    } else {
+        g->head_n = lo - b;
+        g->tail_n = e - hi;
+    }
+    if (g->head_n) {
+        g->head = (unsigned char *)malloc(g->head_n);
+        if (!g->head)
+            return -1;
+        memcpy(g->head, (const void *)b, g->head_n);
+    }
+    if (g->tail_n) {
+        g->tail = (unsigned char *)malloc(g->tail_n);
+        if (!g->tail)
+            return -1;
+        memcpy(g->tail, (const void *)hi, g->tail_n);
+    }
+    g->lo = (char *)lo;
+    g->hi = (char *)hi;
+    if (hi > lo && mprotect((void *)lo, hi - lo, PROT_READ) != 0) {
+        g->lo = g->hi = (char *)e;
+        return -2; /* cannot protect this memory */
+    }
+    return 0;
+}
+
+static int guard_fragments_changed(const guard *g)
+{
+    if (g->head_n && memcmp(g->head, g->p, g->head_n) != 0)
+        return 1;
+    if (g->tail_n && memcmp(g->tail, g->p + g->bytes - g->tail_n, g->tail_n) != 0)
+        return 1;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- slots */
+
+static void slot_drop(slot *sl)
+{
+    if (!sl->used)
+        return;
+    if (sl->armed) {
+        sl->armed = 0;
+        for (int k = 0; k < 3; ++k)
+            guard_unprotect(&sl->g[k]);
+    }
+    for (int k = 0; k < 3; ++k)
+        guard_free(&sl->g[k]);
+    for (int p = 0; p < sl->nparts; ++p) {
+        spmv_hip_matrix_destroy(sl->part[p]);
+        spmv_hip_free(sl->part_dev[p], sl->dx[p]);
+        spmv_hip_free(sl->part_dev[p], sl->dy[p]);
+    }
+    if (G.last == sl)
+        G.last = NULL;
+    memset(sl, 0, sizeof *sl);
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v)
+        return dflt;
+    return atoi(v);
+}
+
+static void print_stats(void)
+{
+    const spmv_hip_stats *s = &G.st;
+    fprintf(stderr,
+            "libhip-spmv: calls=%lld uploads=%lld invalidations=%lld init=%.3fs upload=%.3fs "
+            "x_h2d=%.3fs kernel=%.3fs y_d2h=%.3fs total=%.3fs\n",
+            (long long)s->calls, (long long)s->uploads, (long long)s->invalidations, s->t_init,
+            s->t_upload, s->t_x_h2d, s->t_kernel, s->t_y_d2h, s->t_total);
+}
+
+void spmv_hip_release(void)
+{
+    pthread_mutex_lock(&g_mu);
+    for (int s = 0; s < MAX_SLOTS; ++s)
+        slot_drop(&G.slots[s]);
+    for (int r = 0; r < G.nreg; ++r)
+        spmvd_host_unregister(G.reg[r].lo);
+    G.nreg = 0;
+    spmvd_host_free(G.xstage);
+    spmvd_host_free(G.ystage);
+    G.xstage = G.ystage = NULL;
+    G.xstage_n = G.ystage_n = 0;
+    if (G.handler_installed) {
+        struct sigaction cur;
+        if (sigaction(SIGSEGV, NULL, &cur) == 0 && (cur.sa_flags & SA_SIGINFO) &&
+            cur.sa_sigaction == on_segv)
+            sigaction(SIGSEGV, &G.old_sa, NULL);
+        G.handler_installed = 0;
+    }
+    pthread_mutex_unlock(&g_mu);
+}
+
+/*
+ * Teardown.  Registered with atexit() from lazy_init, i.e. AFTER the HIP
+ * runtime has initialised, so it runs BEFORE the runtime's own exit handlers
+ * (handlers run in reverse order of registration) and, being registered from
+ * inside this DSO, also when the library is dlclose()d (pagerank does that,
+ * /root/reference/pagerank/main.cpp:25-30).
+ */
+static void lib_fini(void)
+{
+    if (!G.inited)
+        return;
+    if (G.stats)
+        print_stats();
+    spmv_hip_release();
+    G.inited = 0;
+}
+
+static void lazy_init(void)
+{
+    if (G.inited)
+        return;
+    double t0 = spmv_now();
+    G.page = sysconf(_SC_PAGESIZE);
+    const char *v;
+
+    G.cache = CACHE_MPROTECT;
+    if ((v = getenv("SPMV_HIP_CACHE"))) {
+        if (!strcmp(v, "pointer") || !strcmp(v, "unsafe"))
+            G.cache = CACHE_POINTER;
+        else if (!strcmp(v, "off") || !strcmp(v, "slow"))
+            G.cache = CACHE_OFF;
+        else if (strcmp(v, "mprotect"))
+            die("SPMV_HIP_CACHE=%s: expected mprotect|pointer|off", v);
+    }
+    G.pin = PIN_STAGING;
+    if ((v = getenv("SPMV_HIP_PIN"))) {
+        if (!strcmp(v, "register"))
+            G.pin = PIN_REGISTER;
+        else if (!strcmp(v, "pageable"))
+            G.pin = PIN_PAGEABLE;
+        else if (strcmp(v, "staging"))
+            die("SPMV_HIP_PIN=%s: expected staging|register|pageable", v);
+    }
+    G.plan = SPMV_HIP_PLAN_AUTO;
+    G.plan_param = 0;
+    if ((v = getenv("SPMV_HIP_PLAN"))) {
+        if (!strcmp(v, "ordered"))
+            G.plan = SPMV_HIP_PLAN_ORDERED;
+        else if (!strcmp(v, "stream"))
+            G.plan = SPMV_HIP_PLAN_STREAM;
+        else if (!strncmp(v, "vector", 6)) {
+            G.plan = SPMV_HIP_PLAN_VECTOR;
+            G.plan_param = v[6] == ':' ? atoi(v + 7) : 64;
+        } else if (!strcmp(v, "binned"))
+            G.plan = SPMV_HIP_PLAN_BINNED;
+        else if (strcmp(v, "auto"))
+            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned", v);
+    }
+    G.stats = env_int("SPMV_HIP_STATS", 0);
+    G.verbose = env_int("SPMV_HIP_VERBOSE", 0);
+    G.nslots = env_int("SPMV_HIP_CACHE_SLOTS", 4);
+    if (G.nslots < 1)
+        G.nslots = 1;
+    if (G.nslots > MAX_SLOTS)
+        G.nslots = MAX_SLOTS;
+
+    int visible = spmv_hip_device_count();
+    if (visible <= 0)
+        die("no HIP device is visible (this backend has no CPU fallback)");
+    G.ndev = 1;
+    if ((v = getenv("SPMV_HIP_DEVICES")))
+        G.ndev = !strcmp(v, "all") ? visible : atoi(v);
+    if (G.ndev < 1 || G.ndev > visible)
+        die("SPMV_HIP_DEVICES=%d but %d device(s) visible", G.ndev, visible);
+    if (G.ndev > MAX_PARTS)
+        G.ndev = MAX_PARTS;
+    G.nparts = env_int("SPMV_HIP_PARTS", G.ndev);
+    if (G.nparts < 1 || G.nparts > MAX_PARTS)
+        die("SPMV_HIP_PARTS must be in [1,%d]", MAX_PARTS);
+
+    /* touch device 0 now so that the context / code-object load is attributed to init */
+    void *probe = spmv_hip_malloc(0, 256);
+    if (!probe)
+        die("device initialisation failed: %s", spmv_hip_last_error());
+    spmv_hip_free(0, probe);
+    atexit(lib_fini);
+    G.inited = 1;
+    G.st.t_init = spmv_now() - t0;
+}
+
+static slot *slot_find(const void *a, const int *rowstr, const int *colidx, int rows, int64_t nnz,
+                       int elem)
+{
+    for (int s = 0; s < G.nslots; ++s) {
+        slot *sl = &G.slots[s];
+        if (sl->used && sl->elem == elem && sl->a == a && sl->rowstr == rowstr && sl->colidx == colidx &&
+            sl->rows == rows && sl->nnz == nnz)
+            return sl;
+    }
+    return NULL;
+}
+
+static slot *slot_victim(void)
+{
+    slot *best = NULL;
+    for (int s = 0; s < G.nslots; ++s) {
+        slot *sl = &G.slots[s];
+        if (!sl->used)
+            return sl;
+        if (!best || sl->last_use < best->last_use)
+            best = sl;
+    }
+    slot_drop(best);
+    return best;
+}
+
+static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *colidx, int rows,
+                        int64_t nnz, int elem)
+{
+    double t0 = spmv_now();
+    memset(sl, 0, sizeof *sl);
+    sl->used = 1;
+    sl->elem = elem;
+    sl->a = a;
+    sl->rowstr = rowstr;
+    sl->colidx = colidx;
+    sl->rows = rows;
+    sl->nnz = nnz;
+    sl->first = rowstr[0];
+    sl->nparts = G.nparts > rows ? (rows > 0 ? rows : 1) : G.nparts;
+    spmv_hip_partition_rows(rowstr, rows, sl->nparts, sl->bounds);
+
+    int cols = 0;
+    for (int p = 0; p < sl->nparts; ++p) {
+        int dev = p % G.ndev;
+        sl->part_dev[p] = dev;
+        sl->part[p] = spmv_hip_matrix_create(a, rowstr, colidx, rows, elem, dev, sl->bounds[p],
+                                             sl->bounds[p + 1], sl->nparts == 1 ? 0 : cols);
+        if (!sl->part[p])
+            die("matrix upload failed: %s", spmv_hip_last_error());
+        if (G.plan != SPMV_HIP_PLAN_AUTO)
+            CHECK(spmv_hip_matrix_set_plan(sl->part[p], G.plan, G.plan_param));
+        spmv_hip_info inf;
+        spmv_hip_matrix_info(sl->part[p], &inf);
+        cols = inf.cols; /* part 0 scans the whole colidx; later parts reuse it */
+    }
+    sl->cols = cols;
+    for (int p = 0; p < sl->nparts; ++p) {
+        int dev = sl->part_dev[p];
+        size_t prow = (size_t)(sl->bounds[p + 1] - sl->bounds[p]);
+        sl->dx[p] = spmv_hip_malloc(dev, ((size_t)cols + 1) * elem);
+        sl->dy[p] = spmv_hip_malloc(dev, (prow + 1) * elem);
+        if (!sl->dx[p] || !sl->dy[p])
+            die("vector allocation failed: %s", spmv_hip_last_error());
+    }
+
+    /* arm write detection AFTER the upload (the copies read the arrays) */
+    if (G.cache != CACHE_OFF) {
+        const int protect = (G.cache == CACHE_MPROTECT);
+        const size_t off = (size_t)(rowstr[0] - 1);
+        const void *ptrs[3] = {(const char *)a + off * elem, rowstr, colidx + off};
+        const size_t lens[3] = {(size_t)nnz * elem, ((size_t)rows + 1) * sizeof(int),
+                                (size_t)nnz * sizeof(int)};
+        if (protect)
+            install_handler();
+        int ok = 1;
+        sl->armed = protect ? 1 : 0; /* set before protecting: a fault may come at once */
+        for (int k = 0; k < 3 && ok; ++k) {
+            int rc = guard_arm(&sl->g[k], ptrs[k], lens[k], protect);
+            if (rc == -1)
+                die("out of host memory arming write detection");
+            if (rc == -2)
+                ok = 0;
+        }
+        if (!ok) {
+            /* memory that cannot be mprotect'ed: be safe, fall back to upload-per-call for it */
+            if (G.verbose)
+                fprintf(stderr, "libhip-spmv: mprotect failed (%s); matrix will not be cached\n",
+                        strerror(errno));
+            sl->armed = 0;
+            for (int k = 0; k < 3; ++k)
+                guard_unprotect(&sl->g[k]);
+            sl->dirty = 1;
+        }
+    }
+    G.st.uploads++;
+    G.st.t_upload += spmv_now() - t0;
+    if (G.verbose) {
+        spmv_hip_info inf;
+        spmv_hip_matrix_info(sl->part[0], &inf);
+        fprintf(stderr,
+                "libhip-spmv: uploaded %s matrix rows=%d cols=%d nnz=%lld parts=%d plan=%d/%d "
+                "(row len %d..%d, mean %.1f) in %.3f s\n",
+                elem == 8 ? "f64" : "f32", rows, cols, (long long)nnz, sl->nparts, inf.plan,
+                inf.plan_param, inf.min_row_len, inf.max_row_len, inf.mean_row_len, spmv_now() - t0);
+    }
+}
+
+/* ---------------------------------------------------------------- pinned transfers */
+
+static void *stage_buf(void **buf, size_t *cap, size_t need)
+{
+    if (*cap < need) {
+        spmvd_host_free(*buf);
+        size_t n = need + need / 4 + 4096;
+        *buf = spmvd_host_alloc(n);
+        if (!*buf)
+            die("pinned staging allocation failed: %s", spmv_hip_last_error());
+        *cap = n;
+    }
+    return *buf;
+}
+
+/* SPMV_HIP_PIN=register: pin the caller's vector in place (page-rounded), once. */
+static int ensure_registered(const void *p, size_t bytes)
+{
+    char *lo = (char *)((uintptr_t)p / (uintptr_t)G.page * (uintptr_t)G.page);
+    char *hi = (char *)(((uintptr_t)p + bytes + G.page - 1) / (uintptr_t)G.page * (uintptr_t)G.page);
+    for (int r = 0; r < G.nreg; ++r)
+        if (lo >= G.reg[r].lo && hi <= G.reg[r].hi)
+            return 1;
+    for (int r = 0; r < G.nreg; ++r)
+        if (lo < G.reg[r].hi && hi > G.reg[r].lo)
+            return 0; /* overlaps a registered range partially: use staging for this one */
+    if (G.nreg == MAX_REG)
+        return 0;
+    if (spmvd_host_register(lo, (size_t)(hi - lo)) != 0)
+        return 0;
+    G.reg[G.nreg].lo = lo;
+    G.reg[G.nreg].hi = hi;
+    G.nreg++;
+    return 1;
+}
+
+/* ---------------------------------------------------------------- the call */
+
+static void *harness(void *ov, const void *a, const void *iv, const int *rowstr, const int *colidx,
+                     const int *rows_p, int elem)
+{
+    pthread_mutex_lock(&g_mu);
+    const double t_in = spmv_now();
+    const int rows = *rows_p;
+    if (rows <= 0) {
+        pthread_mutex_unlock(&g_mu);
+        return NULL;
+    }
+    const int64_t nnz = (int64_t)rowstr[rows] - (int64_t)rowstr[0];
+    if (nnz <= 0) { /* every row is empty: y = 0 (native-impl.c:6,9), nothing to multiply */
+        memset(ov, 0, (size_t)rows * elem);
+        pthread_mutex_unlock(&g_mu);
+        return NULL;
+    }
+    lazy_init();
+
+    slot *sl = slot_find(a, rowstr, colidx, rows, nnz, elem);
+    if (sl) {
+        int stale = (G.cache == CACHE_OFF) || sl->dirty || sl->first != rowstr[0];
+        if (!stale && G.cache == CACHE_MPROTECT)
+            for (int k = 0; k < 3 && !stale; ++k)
+                stale = guard_fragments_changed(&sl->g[k]);
+        if (stale) {
+            if (G.cache != CACHE_OFF) {
+                G.st.invalidations++;
+                if (G.verbose)
+                    fprintf(stderr, "libhip-spmv: host arrays changed, dropping the device copy\n");
+            }
+            slot_drop(sl);
+            sl = NULL;
+        }
+    }
+    if (!sl) {
+        sl = slot_victim();
+        slot_upload(sl, a, rowstr, colidx, rows, nnz, elem);
+    }
+    sl->last_use = ++G.tick;
+    G.last = sl;
+
+    const size_t xbytes = (size_t)sl->cols * elem;
+    const size_t ybytes = (size_t)rows * elem;
+    const int detailed = G.stats >= 2;
+    double t0 = spmv_now(), t1;
+
+    /* x: host -> every part's device (libspmv/gpu.c:264) */
+    const void *xsrc = iv;
+    if (G.pin == PIN_STAGING || (G.pin == PIN_REGISTER && !ensure_registered(iv, xbytes))) {
+        void *xs = stage_buf(&G.xstage, &G.xstage_n, xbytes);
+        memcpy(xs, iv, xbytes);
+        xsrc = xs;
+    }
+    for (int p = 0; p < sl->nparts; ++p)
+        CHECK(spmvd_copy_h2d_async(sl->part_dev[p], sl->dx[p], xsrc, xbytes));
+    if (detailed) {
+        for (int p = 0; p < sl->nparts; ++p)
+            CHECK(spmvd_stream_sync(sl->part_dev[p]));
+        t1 = spmv_now();
+        G.st.t_x_h2d += t1 - t0;
+        t0 = t1;
+    }
+
+    /* y_part = A_part * x, one launch sequence per part, each on its device's stream */
+    for (int p = 0; p < sl->nparts; ++p)
+        CHECK(spmv_hip_spmv_device(sl->part[p], sl->dx[p], sl->dy[p], NULL));
+    if (detailed) {
+        for (int p = 0; p < sl->nparts; ++p)
+            CHECK(spmvd_stream_sync(sl->part_dev[p]));
+        t1 = spmv_now();
+        G.st.t_kernel += t1 - t0;
+        t0 = t1;
+    }
+
+    /* y: each part's slice straight to its place in ov -- the host gather (libspmv/gpu.c:285) */
+    char *ydst = (char *)ov;
+    int y_staged = 0;
+    if (G.pin == PIN_STAGING || (G.pin == PIN_REGISTER && !ensure_registered(ov, ybytes))) {
+        ydst = (char *)stage_buf(&G.ystage, &G.ystage_n, ybytes);
+        y_staged = 1;
+    }
+    for (int p = 0; p < sl->nparts; ++p) {
+        size_t r0 = (size_t)sl->bounds[p], r1 = (size_t)sl->bounds[p + 1];
+        if (r1 > r0)
+            CHECK(spmvd_copy_d2h_async(sl->part_dev[p], ydst + r0 * elem, sl->dy[p], (r1 - r0) * elem));
+    }
+    for (int p = 0; p < sl->nparts; ++p)
+        CHECK(spmvd_stream_sync(sl->part_dev[p]));
+    if (y_staged)
+        memcpy(ov, ydst, ybytes);
+    if (detailed)
+        G.st.t_y_d2h += spmv_now() - t0;
+
+    G.st.calls++;
+    G.st.t_total += spmv_now() - t_in;
+    pthread_mutex_unlock(&g_mu);
+    return NULL;
+}
+
+void *spmv_harness_(double *ov, double *a, double *iv, int *rowstr, int *colidx, int *rows)
+{
+    return harness(ov, a, iv, rowstr, colidx, rows, 8);
+}
+
+void *f_spmv_harness_(float *ov, float *a, float *iv, int *rowstr, int *colidx, int *rows)
+{
+    return harness(ov, a, iv, rowstr, colidx, rows, 4);
+}
+
+/* ---------------------------------------------------------------- introspection */
+
+void spmv_hip_get_stats(spmv_hip_stats *out)
+{
+    pthread_mutex_lock(&g_mu);
+    *out = G.st;
+    pthread_mutex_unlock(&g_mu);
+}
+
+void spmv_hip_reset_stats(void)
+{
+    pthread_mutex_lock(&g_mu);
+    double keep = G.st.t_init;
+    memset(&G.st, 0, sizeof G.st);
+    G.st.t_init = keep;
+    pthread_mutex_unlock(&g_mu);
+}
+
+int spmv_hip_abi_matrix_info(spmv_hip_info *out)
+{
+    int rc = -1;
+    pthread_mutex_lock(&g_mu);
+    if (G.last && G.last->used && G.last->part[0]) {
+        rc = spmv_hip_matrix_info(G.last->part[0], out);
+        if (rc == 0 && G.last->nparts > 1) { /* report the whole matrix, not part 0 */
+            out->rows = G.last->rows;
+            out->nnz = G.last->nnz;
+            out->algorithmic_bytes = G.last->nnz * (int64_t)(G.last->elem + 4) +
+                                     ((int64_t)G.last->rows + 1) * 4 +
+                                     (int64_t)G.last->cols * G.last->elem +
+                                     (int64_t)G.last->rows * G.last->elem;
+        }
+    }
+    pthread_mutex_unlock(&g_mu);
+    return rc;
+}

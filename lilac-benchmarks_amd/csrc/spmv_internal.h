@@ -1,0 +1,129 @@
+/*
+ * csrc/spmv_internal.h -- declarations shared by the C host side
+ * (spmv_harness.c, spmv_plan.c) and the thin HIP layer (spmv_device.hip,
+ * spmv_kernels.hip).  C-compatible on purpose: the host side is plain C.
+ */
+#ifndef SPMV_INTERNAL_H
+#define SPMV_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "spmv_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- geometry constants of the kernels (one place, used by host and device) -- */
+#define SPMV_WG 256               /* threads per workgroup = 4 wavefronts of 64             */
+#define SPMV_STREAM_NPT 8         /* nonzeros per thread per row block in the STREAM kernel  */
+#define SPMV_STREAM_CAP (SPMV_WG * SPMV_STREAM_NPT) /* = 2048 nonzeros per row block         */
+#define SPMV_STREAM_ROWCAP 512    /* rows per row block (row pointers staged in LDS)          */
+#define SPMV_LONG_SEG 16384       /* nonzeros per workgroup in the long-row kernel            */
+#define SPMV_PAD_ELEMS 4096       /* a/colidx are over-allocated by this many entries         */
+                                  /* (a = 0, colidx = 1) so aligned vector loads may overrun  */
+#define SPMV_NBINS 4              /* BINNED plan: lanes per row 1 / 4 / 16 / 64               */
+
+/* ---- host-side row statistics (spmv_plan.c) -------------------------------- */
+typedef struct spmv_row_stats {
+    int rows;
+    int64_t nnz;
+    int min_len, max_len;
+    int empty_rows;
+    double mean_len;
+    double cv_len;       /* stddev / mean of the row length                              */
+    int64_t hist[33];    /* hist[0]: len 0; hist[k]: 2^(k-1) <= len < 2^k                 */
+} spmv_row_stats;
+
+/* rowstr is 1-based CSR as given by the caller; rows [r0,r1). */
+void spmv_plan_row_stats(const int *rowstr, int r0, int r1, spmv_row_stats *st);
+
+/*
+ * STREAM plan.  Row blocks are runs of whole consecutive rows whose nonzeros
+ * total <= cap_nnz and whose count <= cap_rows; a row longer than cap_nnz forms
+ * a block of its own that the stream kernel skips and the long-row kernels take.
+ *
+ *   blk[2*b+0] = first row of block b (local, 0-based)
+ *   blk[2*b+1] = first nonzero of block b (local, 0-based)
+ *   entry nblk is the sentinel {rows, nnz}.
+ *
+ *   seg[4*s+0] = row, seg[4*s+1] = first nnz, seg[4*s+2] = end nnz,
+ *   seg[4*s+3] = partial-sum slot, or -1 when the row has one segment and the
+ *                kernel stores y directly.
+ *   lrow[3*k+0] = row, lrow[3*k+1] = first slot, lrow[3*k+2] = end slot
+ *                 (rows with > 1 segment only; reduced in slot order, which
+ *                 keeps the result reproducible).
+ */
+typedef struct spmv_stream_plan {
+    int nblk;
+    int *blk;
+    int nseg;
+    int *seg;
+    int nlrow;
+    int *lrow;
+    int nslots;
+    int n_long_rows;
+} spmv_stream_plan;
+
+int spmv_plan_stream_build(const int *rowstr, int r0, int r1, int cap_nnz, int cap_rows, int long_seg,
+                           spmv_stream_plan *out);
+void spmv_plan_stream_free(spmv_stream_plan *p);
+
+/*
+ * BINNED plan: rows sorted (stably, so neighbours stay neighbours) into
+ * SPMV_NBINS length classes; bin_rows holds the row ids bin after bin,
+ * bin_off[b]..bin_off[b+1] delimits bin b.  Rows longer than cap_nnz are left
+ * out (long-row kernels take them; the stream plan lists them).
+ */
+typedef struct spmv_bin_plan {
+    int bin_off[SPMV_NBINS + 1];
+    int *bin_rows;
+} spmv_bin_plan;
+
+int spmv_plan_bins_build(const int *rowstr, int r0, int r1, int cap_nnz, spmv_bin_plan *out);
+void spmv_plan_bins_free(spmv_bin_plan *p);
+int spmv_plan_bin_of_len(int len);    /* 0..SPMV_NBINS-1 */
+int spmv_plan_bin_lanes(int bin);     /* 1, 4, 16, 64    */
+
+/* Adaptive choice (SPMV_HIP_PLAN_AUTO): fills *plan / *param from the row statistics. */
+void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int *plan, int *param);
+
+/* ---- kernel launchers (spmv_kernels.hip); stream is a hipStream_t ---------- */
+typedef struct spmv_dev_csr {
+    const int *rowptr;   /* [rows+1], 0-based, local to the block                         */
+    const int *colidx;   /* [nnz + pad], 1-based column ids (as given by the caller)       */
+    const void *val;     /* [nnz + pad]                                                   */
+    int rows;
+    int64_t nnz;
+    int elem_size;
+} spmv_dev_csr;
+
+int spmvk_ordered(const spmv_dev_csr *m, const void *x, void *y, void *stream);
+int spmvk_vector(const spmv_dev_csr *m, int lanes, const int *row_list, int nrows, const void *x,
+                 void *y, void *stream);
+int spmvk_stream(const spmv_dev_csr *m, const int *blk, int nblk, const void *x, void *y, void *stream);
+int spmvk_long(const spmv_dev_csr *m, const int *seg, int nseg, const int *lrow, int nlrow,
+               void *partials, const void *x, void *y, void *stream);
+/* analysis: max(colidx[0..nnz)) -> *d_out (int, device), must be zeroed first */
+int spmvk_colmax(const int *colidx, int64_t nnz, int *d_out, void *stream);
+/* rowptr0[i] = rowstr[i] - rowstr[0] on device (in place allowed) */
+int spmvk_rebase(int *rowptr, int n_plus_1, int base, void *stream);
+
+/* ---- HIP-side helpers for the C host file (spmv_device.hip) ------------------ */
+void *spmvd_host_alloc(size_t bytes);            /* pinned host memory */
+void spmvd_host_free(void *p);
+int spmvd_host_register(void *p, size_t bytes);  /* pin caller memory in place */
+void spmvd_host_unregister(void *p);
+int spmvd_copy_h2d_async(int device, void *dst_dev, const void *src, size_t bytes);
+int spmvd_copy_d2h_async(int device, void *dst, const void *src_dev, size_t bytes);
+int spmvd_stream_sync(int device);
+
+/* ---- misc ------------------------------------------------------------------- */
+void spmv_set_error(const char *fmt, ...);
+double spmv_now(void); /* seconds, CLOCK_MONOTONIC */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

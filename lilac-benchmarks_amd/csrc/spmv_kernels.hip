@@ -1,0 +1,530 @@
+/*
+ * csrc/spmv_kernels.hip -- hand-written CDNA4 (gfx950) kernels for CSR y = A*x.
+ *
+ * These replace the closed cusparse{D,S}csrmv_mp call of the reference GPU
+ * backend (/root/reference/libspmv/gpu.c:270-282 and :350-362); the arithmetic
+ * they must reproduce is /root/reference/libspmv/native-impl.c:1-25.
+ *
+ * The product is an HBM-bound integer/gather stream (AI = 0.166 flop/B for
+ * FP64), so there is no MFMA anywhere: what matters is that a[] and colidx[]
+ * are read exactly once with 16-byte-per-lane coalesced loads, that x[] stays
+ * in L2, and that enough bytes are in flight per CU.
+ *
+ * Kernel family (all 256-thread workgroups = 4 wavefronts of 64):
+ *
+ *   k_ordered   one lane per row, sequential, multiply then add with FP
+ *               contraction off: bit-identical to the reference loop.
+ *   k_vector    L lanes per row (L = 1,2,4,...,64; L = 64 is one wavefront per
+ *               row), 16-byte aligned vector loads of a/colidx straight from
+ *               global memory, DPP reduction inside the lane group.
+ *   k_stream    row-segment kernel: a workgroup owns a run of whole rows with
+ *               <= 2044 nonzeros, streams a/colidx coalesced regardless of where
+ *               rows start, multiplies by the gathered x, parks the products in
+ *               LDS, then lane groups (1..64 lanes, chosen per block) reduce each
+ *               row out of LDS.
+ *   k_long      rows longer than a row block: one workgroup per 16384-nonzero
+ *               segment, partial sums combined in fixed order by k_long_finish
+ *               (no float atomics: results are reproducible run to run).
+ *
+ * Column ids stay 1-based as the ABI delivers them; kernels index x through
+ * (x - 1).  a/colidx are over-allocated by SPMV_PAD_ELEMS entries (a = 0,
+ * colidx = 1) so that aligned vector loads may run past a row's end.
+ */
+#include <hip/hip_runtime.h>
+
+#include "spmv_internal.h"
+
+namespace {
+
+/* ---- tuning switches (set through spmvk_set_tuning; experiments only) ------- */
+int g_tune_xcd = 1;     /* give each XCD a contiguous range of row blocks        */
+int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx        */
+
+/* ---- 16-byte vector types --------------------------------------------------- */
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Vec16;
+template <> struct Vec16<double> {
+    using val_t = f64x2;
+    using idx_t = i32x2;
+    static constexpr int E = 2;
+};
+template <> struct Vec16<float> {
+    using val_t = f32x4;
+    using idx_t = i32x4;
+    static constexpr int E = 4;
+};
+
+template <typename V, bool NT> __device__ __forceinline__ V ld(const V *p)
+{
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+
+
+__device__ __forceinline__ double fmadd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fmadd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+/* ---- DPP cross-lane adds ------------------------------------------------------ */
+/* One DPP move of a 32- or 64-bit value; lanes whose source is disabled by
+ * row_mask read 0 (old = 0, bound_ctrl off). */
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov(double v)
+{
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    long long r = ((long long)hi << 32) | (unsigned int)lo;
+    return __builtin_bit_cast(double, r);
+}
+
+/*
+ * Sum over aligned groups of G consecutive lanes (G = 1..64, power of two).
+ * After the call the LAST lane of every group holds the group's sum (for
+ * G <= 16 every lane does).  The order of the additions is fixed by G alone,
+ * so a row's result does not depend on which lanes it landed on.
+ */
+template <typename T, int G> __device__ __forceinline__ T group_sum(T v)
+{
+    if constexpr (G >= 2)
+        v += dpp_mov<0xB1, 0xf>(v); /* quad_perm [1,0,3,2] */
+    if constexpr (G >= 4)
+        v += dpp_mov<0x4E, 0xf>(v); /* quad_perm [2,3,0,1] */
+    if constexpr (G >= 8)
+        v += dpp_mov<0x141, 0xf>(v); /* row_half_mirror     */
+    if constexpr (G >= 16)
+        v += dpp_mov<0x140, 0xf>(v); /* row_mirror          */
+    if constexpr (G >= 32)
+        v += dpp_mov<0x142, 0xa>(v); /* row_bcast:15 -> rows 1,3 */
+    if constexpr (G >= 64)
+        v += dpp_mov<0x143, 0xc>(v); /* row_bcast:31 -> rows 2,3 */
+    return v;
+}
+
+/* Blocks b, b+8, b+16, ... share an XCD (and its L2): hand every XCD one
+ * contiguous range of work items so neighbouring row blocks share cache lines
+ * and x-locality inside one L2.  Launch with grid = 8 * ceil(n/8); ids >= n idle. */
+__device__ __forceinline__ int xcd_contiguous(int b, int per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
+
+/* ================================ k_ordered ===================================== */
+template <typename T>
+__global__ void __launch_bounds__(SPMV_WG) k_ordered(const int *__restrict__ rowptr,
+                                                     const int *__restrict__ colidx,
+                                                     const T *__restrict__ val,
+                                                     const T *__restrict__ xm1, T *__restrict__ y,
+                                                     int rows)
+{
+#pragma clang fp contract(off)
+    const int r = blockIdx.x * SPMV_WG + threadIdx.x;
+    if (r >= rows)
+        return;
+    const int s = rowptr[r], e = rowptr[r + 1];
+    T acc = (T)0;
+    for (int j = s; j < e; ++j) {
+        T p = val[j] * xm1[colidx[j]];
+        acc = acc + p;
+    }
+    y[r] = acc;
+}
+
+/* ================================ k_vector ====================================== */
+template <typename T, int L, bool LIST, bool NT>
+__global__ void __launch_bounds__(SPMV_WG) k_vector(const int *__restrict__ rowptr,
+                                                    const int *__restrict__ colidx,
+                                                    const T *__restrict__ val,
+                                                    const T *__restrict__ xm1, T *__restrict__ y,
+                                                    const int *__restrict__ row_list, int nrows,
+                                                    int per_xcd)
+{
+    using VT = typename Vec16<T>::val_t;
+    using IT = typename Vec16<T>::idx_t;
+    constexpr int E = Vec16<T>::E;
+    constexpr int RPB = SPMV_WG / L; /* rows per workgroup */
+
+    const int tid = threadIdx.x;
+    const int wg = per_xcd > 0 ? xcd_contiguous(blockIdx.x, per_xcd) : (int)blockIdx.x;
+    const int g = wg * RPB + tid / L;
+    const int lane = tid % L;
+
+    T acc0 = (T)0, acc1 = (T)0;
+    int row = 0;
+    if (g < nrows) {
+        row = LIST ? row_list[g] : g;
+        const int s = rowptr[row], e = rowptr[row + 1];
+        int j = (s & ~(E - 1)) + lane * E;
+        for (; j < e; j += 2 * L * E) {
+            const int j2 = j + L * E;
+            const bool two = j2 < e;
+            IT c0 = ld<IT, NT>(reinterpret_cast<const IT *>(colidx + j));
+            VT v0 = ld<VT, NT>(reinterpret_cast<const VT *>(val + j));
+            IT c1 = c0;
+            VT v1 = v0;
+            if (two) {
+                c1 = ld<IT, NT>(reinterpret_cast<const IT *>(colidx + j2));
+                v1 = ld<VT, NT>(reinterpret_cast<const VT *>(val + j2));
+            }
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int jj = j + i;
+                if (jj >= s && jj < e)
+                    acc0 = fmadd(v0[i], xm1[c0[i]], acc0);
+            }
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const int jj = j2 + i;
+                    if (jj < e)
+                        acc1 = fmadd(v1[i], xm1[c1[i]], acc1);
+                }
+            }
+        }
+    }
+    T acc = group_sum<T, L>(acc0 + acc1);
+    if (g < nrows && lane == L - 1)
+        y[row] = acc;
+}
+
+/* ================================ k_stream ====================================== */
+template <typename T, bool NT>
+__global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
+                                                    const int *__restrict__ rowptr,
+                                                    const int *__restrict__ colidx,
+                                                    const T *__restrict__ val,
+                                                    const T *__restrict__ xm1, T *__restrict__ y,
+                                                    int nblk, int per_xcd)
+{
+    using VT = typename Vec16<T>::val_t;
+    using IT = typename Vec16<T>::idx_t;
+    constexpr int E = Vec16<T>::E;
+    constexpr int CAP = SPMV_STREAM_CAP;
+    constexpr int ROUNDS = CAP / (SPMV_WG * E);
+
+    __shared__ __attribute__((aligned(16))) T s_prod[CAP];
+    __shared__ int s_rp[SPMV_STREAM_ROWCAP + 1];
+
+    const int b = per_xcd > 0 ? xcd_contiguous(blockIdx.x, per_xcd) : (int)blockIdx.x;
+    if (b >= nblk)
+        return;
+    const int tid = threadIdx.x;
+    const i32x2 d0 = *reinterpret_cast<const i32x2 *>(blk + 2 * b);
+    const i32x2 d1 = *reinterpret_cast<const i32x2 *>(blk + 2 * b + 2);
+    const int r0 = d0[0], s = d0[1], r1 = d1[0], e = d1[1];
+    const int nrows = r1 - r0;
+    const int base = s & ~(E - 1);
+    if (e - s > CAP - 4) /* a long row's block (planner cap = CAP - 4): k_long owns it */
+        return;
+
+    /* ---- phase 1: stream a / colidx, gather x, park products in LDS ---- */
+    /* All loads of the block are issued before anything waits on them, with no
+     * branch in between: a lane whose slot lies past the block's end re-reads
+     * its own round-0 slot instead (an L1 hit; at worst SPMV_WG*E entries past a
+     * tiny block's end, inside the SPMV_PAD_ELEMS padding).  Entries before s /
+     * after e belong to neighbouring rows or the padding: their column ids are
+     * valid and their products are never read back. */
+    IT c[ROUNDS];
+    VT v[ROUNDS];
+    const int j0 = base + tid * E;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int j = j0 + k * SPMV_WG * E;
+        const int jl = j < e ? j : j0;
+        c[k] = ld<IT, NT>(reinterpret_cast<const IT *>(colidx + jl));
+        v[k] = ld<VT, NT>(reinterpret_cast<const VT *>(val + jl));
+    }
+    for (int i = tid; i <= nrows; i += SPMV_WG)
+        s_rp[i] = rowptr[r0 + i] - base;
+    T xg[ROUNDS][E];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k)
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            xg[k][i] = xm1[c[k][i]];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        VT p;
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            p[i] = v[k][i] * xg[k][i];
+        *reinterpret_cast<VT *>(&s_prod[(k * SPMV_WG + tid) * E]) = p;
+    }
+    __syncthreads();
+
+    /* ---- phase 2: lane groups reduce whole rows out of LDS ---- */
+    /* G lanes per row, block-uniform: as many as fill the workgroup in one pass,
+     * but no more than the average row offers */
+    const int n = e - s;
+    int G = 64;
+    while (G > 1 && (G * nrows > SPMV_WG || G > 2 * ((n + nrows - 1) / (nrows > 0 ? nrows : 1))))
+        G >>= 1;
+
+#define SPMV_REDUCE_ROWS(GG)                                                         \
+    {                                                                                \
+        constexpr int NG = SPMV_WG / GG;                                             \
+        const int grp = tid / GG, gl = tid % GG;                                     \
+        /* rr is uniform inside a lane group, so every DPP step below only ever   \
+         * combines lanes that are active together */                              \
+        for (int rr = grp; rr < nrows; rr += NG) {                                   \
+            const int ps = s_rp[rr], pe = s_rp[rr + 1];                              \
+            T acc = (T)0;                                                            \
+            for (int k = ps + gl; k < pe; k += GG)                                   \
+                acc += s_prod[k];                                                    \
+            acc = group_sum<T, GG>(acc);                                             \
+            if (gl == GG - 1)                                                        \
+                y[r0 + rr] = acc;                                                    \
+        }                                                                            \
+    }
+    switch (G) {
+    case 64: SPMV_REDUCE_ROWS(64) break;
+    case 32: SPMV_REDUCE_ROWS(32) break;
+    case 16: SPMV_REDUCE_ROWS(16) break;
+    case 8: SPMV_REDUCE_ROWS(8) break;
+    case 4: SPMV_REDUCE_ROWS(4) break;
+    case 2: SPMV_REDUCE_ROWS(2) break;
+    default: SPMV_REDUCE_ROWS(1) break;
+    }
+#undef SPMV_REDUCE_ROWS
+}
+
+/* ================================ k_long ======================================== */
+template <typename T>
+__global__ void __launch_bounds__(SPMV_WG) k_long(const int *__restrict__ seg,
+                                                  const int *__restrict__ colidx,
+                                                  const T *__restrict__ val,
+                                                  const T *__restrict__ xm1, T *__restrict__ y,
+                                                  T *__restrict__ partials)
+{
+    using VT = typename Vec16<T>::val_t;
+    using IT = typename Vec16<T>::idx_t;
+    constexpr int E = Vec16<T>::E;
+    __shared__ T s_w[SPMV_WG / 64];
+
+    const i32x4 d = *reinterpret_cast<const i32x4 *>(seg + 4 * blockIdx.x);
+    const int row = d[0], sb = d[1], se = d[2], slot = d[3];
+    const int tid = threadIdx.x;
+    T acc = (T)0;
+    for (int j = (sb & ~(E - 1)) + tid * E; j < se; j += SPMV_WG * E) {
+        IT c = *reinterpret_cast<const IT *>(colidx + j);
+        VT v = *reinterpret_cast<const VT *>(val + j);
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int jj = j + i;
+            if (jj >= sb && jj < se)
+                acc = fmadd(v[i], xm1[c[i]], acc);
+        }
+    }
+    acc = group_sum<T, 64>(acc);
+    if ((tid & 63) == 63)
+        s_w[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        T t = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+        if (slot < 0)
+            y[row] = t;
+        else
+            partials[slot] = t;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_long_finish(const int *__restrict__ lrow,
+                                                    const T *__restrict__ partials,
+                                                    T *__restrict__ y, int nlrow)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= nlrow)
+        return;
+    const int row = lrow[3 * k], p0 = lrow[3 * k + 1], p1 = lrow[3 * k + 2];
+    T t = (T)0;
+    for (int p = p0; p < p1; ++p)
+        t += partials[p];
+    y[row] = t;
+}
+
+/* ================================ analysis ====================================== */
+__global__ void __launch_bounds__(SPMV_WG) k_colmax(const int *__restrict__ colidx, long long nnz,
+                                                    int *__restrict__ out)
+{
+    int m = 0;
+    for (long long j = (long long)blockIdx.x * SPMV_WG + threadIdx.x; j < nnz;
+         j += (long long)gridDim.x * SPMV_WG) {
+        int c = colidx[j];
+        m = c > m ? c : m;
+    }
+    for (int o = 32; o; o >>= 1) {
+        int t = __shfl_xor(m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(out, m);
+}
+
+__global__ void __launch_bounds__(SPMV_WG) k_rebase(int *__restrict__ rowptr, int n, int base)
+{
+    const int i = blockIdx.x * SPMV_WG + threadIdx.x;
+    if (i < n)
+        rowptr[i] -= base;
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+template <typename T> const T *xm1_of(const void *x) { return reinterpret_cast<const T *>(x) - 1; }
+
+template <typename T, int L>
+int launch_vector(const spmv_dev_csr *m, const int *row_list, int nrows, const void *x, void *y,
+                  hipStream_t st)
+{
+    constexpr int RPB = SPMV_WG / L;
+    const int nwg = (nrows + RPB - 1) / RPB;
+    if (nwg <= 0)
+        return 0;
+    const int per = g_tune_xcd ? (nwg + 7) / 8 : 0;
+    const int grid = per ? per * 8 : nwg;
+    const T *val = reinterpret_cast<const T *>(m->val);
+    T *yy = reinterpret_cast<T *>(y);
+#define SPMV_LV(LIST, NT)                                                                        \
+    hipLaunchKernelGGL((k_vector<T, L, LIST, NT>), dim3(grid), dim3(SPMV_WG), 0, st, m->rowptr,  \
+                       m->colidx, val, xm1_of<T>(x), yy, row_list, nrows, per)
+    if (row_list) {
+        if (g_tune_nt)
+            SPMV_LV(true, true);
+        else
+            SPMV_LV(true, false);
+    } else {
+        if (g_tune_nt)
+            SPMV_LV(false, true);
+        else
+            SPMV_LV(false, false);
+    }
+#undef SPMV_LV
+    return launch_status();
+}
+
+template <typename T>
+int dispatch_vector(const spmv_dev_csr *m, int lanes, const int *row_list, int nrows, const void *x,
+                    void *y, hipStream_t st)
+{
+    switch (lanes) {
+    case 1: return launch_vector<T, 1>(m, row_list, nrows, x, y, st);
+    case 2: return launch_vector<T, 2>(m, row_list, nrows, x, y, st);
+    case 4: return launch_vector<T, 4>(m, row_list, nrows, x, y, st);
+    case 8: return launch_vector<T, 8>(m, row_list, nrows, x, y, st);
+    case 16: return launch_vector<T, 16>(m, row_list, nrows, x, y, st);
+    case 32: return launch_vector<T, 32>(m, row_list, nrows, x, y, st);
+    case 64: return launch_vector<T, 64>(m, row_list, nrows, x, y, st);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+void spmvk_set_tuning(int key, int value)
+{
+    if (key == 0)
+        g_tune_xcd = value;
+    else if (key == 1)
+        g_tune_nt = value;
+}
+
+int spmvk_ordered(const spmv_dev_csr *m, const void *x, void *y, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (m->rows + SPMV_WG - 1) / SPMV_WG;
+    if (grid <= 0)
+        return 0;
+    if (m->elem_size == 8)
+        hipLaunchKernelGGL(k_ordered<double>, dim3(grid), dim3(SPMV_WG), 0, st, m->rowptr, m->colidx,
+                           (const double *)m->val, xm1_of<double>(x), (double *)y, m->rows);
+    else
+        hipLaunchKernelGGL(k_ordered<float>, dim3(grid), dim3(SPMV_WG), 0, st, m->rowptr, m->colidx,
+                           (const float *)m->val, xm1_of<float>(x), (float *)y, m->rows);
+    return launch_status();
+}
+
+int spmvk_vector(const spmv_dev_csr *m, int lanes, const int *row_list, int nrows, const void *x,
+                 void *y, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    return m->elem_size == 8 ? dispatch_vector<double>(m, lanes, row_list, nrows, x, y, st)
+                             : dispatch_vector<float>(m, lanes, row_list, nrows, x, y, st);
+}
+
+int spmvk_stream(const spmv_dev_csr *m, const int *blk, int nblk, const void *x, void *y, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (nblk <= 0)
+        return 0;
+    const int per = g_tune_xcd ? (nblk + 7) / 8 : 0;
+    const int grid = per ? per * 8 : nblk;
+#define SPMV_LS(T, NT)                                                                          \
+    hipLaunchKernelGGL((k_stream<T, NT>), dim3(grid), dim3(SPMV_WG), 0, st, blk, m->rowptr,     \
+                       m->colidx, (const T *)m->val, xm1_of<T>(x), (T *)y, nblk, per)
+    if (m->elem_size == 8) {
+        if (g_tune_nt)
+            SPMV_LS(double, true);
+        else
+            SPMV_LS(double, false);
+    } else {
+        if (g_tune_nt)
+            SPMV_LS(float, true);
+        else
+            SPMV_LS(float, false);
+    }
+#undef SPMV_LS
+    return launch_status();
+}
+
+int spmvk_long(const spmv_dev_csr *m, const int *seg, int nseg, const int *lrow, int nlrow,
+               void *partials, const void *x, void *y, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (nseg <= 0)
+        return 0;
+    if (m->elem_size == 8) {
+        hipLaunchKernelGGL(k_long<double>, dim3(nseg), dim3(SPMV_WG), 0, st, seg, m->colidx,
+                           (const double *)m->val, xm1_of<double>(x), (double *)y, (double *)partials);
+        if (nlrow > 0)
+            hipLaunchKernelGGL(k_long_finish<double>, dim3((nlrow + 63) / 64), dim3(64), 0, st, lrow,
+                               (const double *)partials, (double *)y, nlrow);
+    } else {
+        hipLaunchKernelGGL(k_long<float>, dim3(nseg), dim3(SPMV_WG), 0, st, seg, m->colidx,
+                           (const float *)m->val, xm1_of<float>(x), (float *)y, (float *)partials);
+        if (nlrow > 0)
+            hipLaunchKernelGGL(k_long_finish<float>, dim3((nlrow + 63) / 64), dim3(64), 0, st, lrow,
+                               (const float *)partials, (float *)y, nlrow);
+    }
+    return launch_status();
+}
+
+int spmvk_colmax(const int *colidx, int64_t nnz, int *d_out, void *stream)
+{
+    if (nnz <= 0)
+        return 0;
+    long long want = (nnz + SPMV_WG - 1) / SPMV_WG;
+    int grid = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_colmax, dim3(grid), dim3(SPMV_WG), 0, (hipStream_t)stream, colidx,
+                       (long long)nnz, d_out);
+    return launch_status();
+}
+
+int spmvk_rebase(int *rowptr, int n_plus_1, int base, void *stream)
+{
+    if (n_plus_1 <= 0 || base == 0)
+        return 0;
+    hipLaunchKernelGGL(k_rebase, dim3((n_plus_1 + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0,
+                       (hipStream_t)stream, rowptr, n_plus_1, base);
+    return launch_status();
+}
+
+} // extern "C"

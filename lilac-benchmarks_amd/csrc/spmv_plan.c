@@ -1,0 +1,268 @@
+/*
+ * csrc/spmv_plan.c -- host-side planning for the HIP SpMV backend (plain C).
+ *
+ * Everything here works on the caller's own 1-based `rowstr` array in host
+ * memory (the ABI hands it over anyway, /root/reference/libspmv/native.c:3),
+ * costs O(rows), and runs once per cached matrix:
+ *
+ *   - row-length statistics that drive the adaptive kernel choice (the
+ *     reference has a precedent for per-matrix dispatch in
+ *     libspmv/mkl-model.c:152-165, there between MKL and the native loop);
+ *   - the row-block list of the STREAM kernel and the segment list of the
+ *     long-row kernels;
+ *   - the row bins of the BINNED plan;
+ *   - the block-row partition across GPUs.
+ *
+ * No GPU is needed to run or test any of it.
+ */
+#include "spmv_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int row_len(const int *rowstr, int r) { return rowstr[r + 1] - rowstr[r]; }
+
+void spmv_plan_row_stats(const int *rowstr, int r0, int r1, spmv_row_stats *st)
+{
+    memset(st, 0, sizeof *st);
+    st->rows = r1 - r0;
+    if (st->rows <= 0) {
+        st->rows = 0;
+        return;
+    }
+    st->nnz = (int64_t)rowstr[r1] - (int64_t)rowstr[r0];
+    st->min_len = 0x7fffffff;
+    double sumsq = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        int len = row_len(rowstr, r);
+        if (len < st->min_len)
+            st->min_len = len;
+        if (len > st->max_len)
+            st->max_len = len;
+        if (len <= 0) {
+            st->empty_rows++;
+            st->hist[0]++;
+        } else {
+            int k = 1;
+            while ((len >> k) != 0)
+                ++k; /* 2^(k-1) <= len < 2^k */
+            st->hist[k > 32 ? 32 : k]++;
+        }
+        sumsq += (double)len * (double)len;
+    }
+    st->mean_len = (double)st->nnz / (double)st->rows;
+    double var = sumsq / (double)st->rows - st->mean_len * st->mean_len;
+    st->cv_len = (st->mean_len > 0 && var > 0) ? sqrt(var) / st->mean_len : 0.0;
+}
+
+/* ---- STREAM row blocks + long-row segments ---------------------------------- */
+
+typedef struct ivec {
+    int *p;
+    size_t n, cap;
+} ivec;
+
+static int ivec_push(ivec *v, int x)
+{
+    if (v->n == v->cap) {
+        size_t nc = v->cap ? v->cap * 2 : 1024;
+        int *np = (int *)realloc(v->p, nc * sizeof(int));
+        if (!np)
+            return -1;
+        v->p = np;
+        v->cap = nc;
+    }
+    v->p[v->n++] = x;
+    return 0;
+}
+
+int spmv_plan_stream_build(const int *rowstr, int r0, int r1, int cap_nnz, int cap_rows, int long_seg,
+                           spmv_stream_plan *out)
+{
+    memset(out, 0, sizeof *out);
+    ivec blk = {0}, seg = {0}, lrow = {0};
+    const int base = rowstr[r0];
+    int rows = r1 - r0;
+    int bstart = 0;     /* first row of the block being filled (local)        */
+    int bnnz = 0;       /* nonzeros in it so far                              */
+    int err = 0;
+
+#define PUSH_BLOCK(row)                                                      \
+    do {                                                                     \
+        err |= ivec_push(&blk, (row));                                       \
+        err |= ivec_push(&blk, rowstr[r0 + (row)] - base);                   \
+    } while (0)
+
+    if (rows > 0)
+        PUSH_BLOCK(0);
+    for (int r = 0; r < rows && !err; ++r) {
+        int len = row_len(rowstr, r0 + r);
+        if (len > cap_nnz) {
+            /* close the running block, emit the long row as a block of its own */
+            if (r > bstart)
+                PUSH_BLOCK(r);
+            int nseg = (len + long_seg - 1) / long_seg;
+            int s0 = rowstr[r0 + r] - base;
+            int slot0 = out->nslots;
+            for (int s = 0; s < nseg; ++s) {
+                int sb = s0 + s * long_seg;
+                int se = sb + long_seg;
+                if (se > s0 + len)
+                    se = s0 + len;
+                err |= ivec_push(&seg, r);
+                err |= ivec_push(&seg, sb);
+                err |= ivec_push(&seg, se);
+                err |= ivec_push(&seg, nseg == 1 ? -1 : out->nslots++);
+            }
+            if (nseg > 1) {
+                err |= ivec_push(&lrow, r);
+                err |= ivec_push(&lrow, slot0);
+                err |= ivec_push(&lrow, out->nslots);
+            }
+            out->n_long_rows++;
+            bstart = r + 1;
+            bnnz = 0;
+            if (bstart < rows)
+                PUSH_BLOCK(bstart);
+            continue;
+        }
+        if (bnnz + len > cap_nnz || r - bstart >= cap_rows) {
+            PUSH_BLOCK(r);
+            bstart = r;
+            bnnz = 0;
+        }
+        bnnz += len;
+    }
+#undef PUSH_BLOCK
+    if (err) {
+        free(blk.p), free(seg.p), free(lrow.p);
+        return -1;
+    }
+    /* the last pushed pair opened a block; count of blocks = pairs, then sentinel */
+    out->nblk = (int)(blk.n / 2);
+    if (ivec_push(&blk, rows) || ivec_push(&blk, rows > 0 ? rowstr[r1] - base : 0)) {
+        free(blk.p), free(seg.p), free(lrow.p);
+        return -1;
+    }
+    out->blk = blk.p;
+    out->nseg = (int)(seg.n / 4);
+    out->seg = seg.p;
+    out->nlrow = (int)(lrow.n / 3);
+    out->lrow = lrow.p;
+    return 0;
+}
+
+void spmv_plan_stream_free(spmv_stream_plan *p)
+{
+    free(p->blk), free(p->seg), free(p->lrow);
+    memset(p, 0, sizeof *p);
+}
+
+/* ---- BINNED plan -------------------------------------------------------------- */
+
+int spmv_plan_bin_of_len(int len)
+{
+    if (len <= 2)
+        return 0;
+    if (len <= 16)
+        return 1;
+    if (len <= 128)
+        return 2;
+    return 3;
+}
+
+int spmv_plan_bin_lanes(int bin)
+{
+    static const int lanes[SPMV_NBINS] = {1, 4, 16, 64};
+    return lanes[bin < 0 ? 0 : (bin >= SPMV_NBINS ? SPMV_NBINS - 1 : bin)];
+}
+
+int spmv_plan_bins_build(const int *rowstr, int r0, int r1, int cap_nnz, spmv_bin_plan *out)
+{
+    memset(out, 0, sizeof *out);
+    int rows = r1 - r0;
+    int count[SPMV_NBINS] = {0};
+    for (int r = 0; r < rows; ++r) {
+        int len = row_len(rowstr, r0 + r);
+        if (len > cap_nnz)
+            continue;
+        count[spmv_plan_bin_of_len(len)]++;
+    }
+    out->bin_off[0] = 0;
+    for (int b = 0; b < SPMV_NBINS; ++b)
+        out->bin_off[b + 1] = out->bin_off[b] + count[b];
+    int total = out->bin_off[SPMV_NBINS];
+    out->bin_rows = (int *)malloc((size_t)(total > 0 ? total : 1) * sizeof(int));
+    if (!out->bin_rows)
+        return -1;
+    int cur[SPMV_NBINS];
+    for (int b = 0; b < SPMV_NBINS; ++b)
+        cur[b] = out->bin_off[b];
+    for (int r = 0; r < rows; ++r) { /* stable: row order kept inside a bin */
+        int len = row_len(rowstr, r0 + r);
+        if (len > cap_nnz)
+            continue;
+        out->bin_rows[cur[spmv_plan_bin_of_len(len)]++] = r;
+    }
+    return 0;
+}
+
+void spmv_plan_bins_free(spmv_bin_plan *p)
+{
+    free(p->bin_rows);
+    memset(p, 0, sizeof *p);
+}
+
+/* ---- adaptive choice ------------------------------------------------------------ */
+
+void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int *plan, int *param)
+{
+    (void)elem_size;
+    /*
+     * The STREAM kernel reads a/colidx with the same coalesced pattern whatever
+     * the row structure, so it is the default.  Matrices whose rows are all long
+     * enough to fill a wavefront's vector loads several times over go to the
+     * wave-per-row VECTOR kernel, which skips the LDS round trip.
+     * (Thresholds from the measurements recorded in DESIGN.md.)
+     */
+    *plan = SPMV_HIP_PLAN_STREAM;
+    *param = SPMV_STREAM_CAP;
+    if (st->rows > 0 && st->min_len >= 96 && st->max_len <= SPMV_STREAM_CAP && st->cv_len < 1.0) {
+        *plan = SPMV_HIP_PLAN_VECTOR;
+        *param = 64;
+    }
+}
+
+/* ---- multi-GPU block-row partition ------------------------------------------------ */
+
+void spmv_hip_partition_rows(const int *rowstr, int rows, int parts, int *bounds)
+{
+    if (parts < 1)
+        parts = 1;
+    bounds[0] = 0;
+    if (rows <= 0) {
+        for (int p = 1; p <= parts; ++p)
+            bounds[p] = 0;
+        return;
+    }
+    const int64_t base = rowstr[0];
+    const int64_t nnz = (int64_t)rowstr[rows] - base;
+    for (int p = 1; p < parts; ++p) {
+        /* first row whose starting offset reaches p/parts of the nonzeros */
+        int64_t target = (nnz * p) / parts;
+        int lo = bounds[p - 1], hi = rows;
+        while (lo < hi) {
+            int mid = lo + (hi - lo) / 2;
+            if ((int64_t)rowstr[mid] - base < target)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        bounds[p] = lo;
+    }
+    bounds[parts] = rows;
+    if (nnz == 0) /* no weights to balance: split rows evenly */
+        for (int p = 1; p < parts; ++p)
+            bounds[p] = (int)(((int64_t)rows * p) / parts);
+}

@@ -1,0 +1,84 @@
+/*
+ * host/npb_cg.h -- our counterpart of the NPB CG caller.
+ *
+ * The reference's Fortran program is not rebuilt; this C library reproduces
+ * what it does around the SpMV boundary so that the backend can be measured and
+ * verified on a box that has neither the reference nor a Fortran compiler:
+ *
+ *   npb_makea      the class matrix, bit-identical to makea/sparse
+ *                  (/root/reference/NPB3.3.1/CG/cg.f:650-905) but built by
+ *                  bucketing + stable sorting instead of ordered insertion, so
+ *                  classes C and D take seconds / minutes instead of hours
+ *   npb_cg_run     the benchmark proper (cg.f:193-402): one untimed conj_grad,
+ *                  niter timed ones, 26 spmv_harness_ calls each (cg.f:532,628),
+ *                  the zeta verification (cg.f:122-163,363-368) and the MOp/s
+ *                  formula (cg.f:395-402)
+ *
+ * The SpMV is called through a function pointer with the ABI's signature so the
+ * same driver runs on libhip-spmv.so, on the oracle, or on the reference's own
+ * native.so.
+ */
+#ifndef NPB_CG_H
+#define NPB_CG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *(*spmv_harness_fn)(double *ov, double *a, double *iv, int *rowstr, int *colidx, int *rows);
+
+typedef struct npb_class {
+    char name;    /* 'S','W','A','B','C','D','E' */
+    int na;
+    int nonzer;
+    int niter;
+    double shift;
+    double rcond;
+    double zeta_verify;
+} npb_class;
+
+typedef struct npb_matrix {
+    npb_class cls;
+    int64_t nnz;
+    int *rowstr;   /* [na+1], 1-based */
+    int *colidx;   /* [nnz],  1-based */
+    double *a;     /* [nnz]           */
+    double t_gen;  /* seconds spent generating */
+} npb_matrix;
+
+#define NPB_MAX_ITER 128
+typedef struct npb_result {
+    char cls;
+    int na, niter;
+    int64_t nnz;
+    int64_t spmv_calls;
+    double zeta, rnorm;
+    double zeta_hist[NPB_MAX_ITER];
+    double rnorm_hist[NPB_MAX_ITER];
+    double err;         /* |zeta - verify| / verify           */
+    int verified;       /* err <= 1e-10 (cg.f:363-368)          */
+    double t_init;      /* s: untimed first conj_grad           */
+    double t_bench;     /* s: "Time in seconds"                 */
+    double t_spmv;      /* s: inside the harness calls (timed part) */
+    double mops;        /* cg.f:395-402                         */
+} npb_result;
+
+/* 0 on success, -1 for an unknown class letter */
+int npb_class_lookup(char name, npb_class *out);
+/* Generates the class matrix.  0 on success; -1 unknown class; -2 out of memory;
+ * -3 the class does not fit int32 indices (class E). */
+int npb_makea(char cls, npb_matrix *out);
+void npb_matrix_free(npb_matrix *m);
+/* Runs the benchmark with `spmv` as the sparse product.  niter_override > 0 shortens the timed loop
+ * (verification is then skipped). */
+int npb_cg_run(const npb_matrix *m, spmv_harness_fn spmv, int niter_override, int verbose,
+               npb_result *out);
+/* Prints the result in the layout of NPB's print_results (common/print_results.f). */
+void npb_print_result(const npb_result *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
