@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the hip-spmv backend (contract: see the task statement).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path: one y = A*x (FP64 CSR) over the whole workload with A, x
+and y already resident in HBM.
+
+  N = 1   workload = BASELINE.json configs[1]: the NPB3.3.1 CG class C matrix (150000 rows,
+          36121058 nonzeros), generated in-process by our restatement of makea.
+  N > 1   workload = BASELINE.json configs[4]: the NPB CG class D matrix (1500000 rows,
+          ~694.4 M nonzeros) row-partitioned over the N ranks (one process per GPU, block rows
+          of about equal nnz, x replicated on every GPU, NO collective on the data path; the
+          caller-visible gather of y is a host copy outside the timed region).  Each rank
+          generates only its own row block.  torch.distributed is used for the barrier and
+          the max-over-ranks of the elapsed time, nothing else.
+
+value = 2 * nnz * K / elapsed  (effective GFLOP/s, whole job).  The same K launches are
+bracketed by HIP events recorded on the stream the kernels run on (spmv_hip_time_device), which
+gives the per-launch duration for the roofline object.  Rank 0 at N = 1 additionally reports
+  * npb_cg: the complete NPB CG class C benchmark through the drop-in ABI (host vectors, PCIe
+    round trip of x and y on each of its 1976 SpMV calls) -> MOp/s by cg.f:395-402, verified
+    against cg.f:122-163;
+  * cpu_baseline: the reference's CPU path (oracle/_ref/native.so when it was built in the
+    authoring container, else our port) on one host core, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cls", default=None, help="override the NPB class (default: C at N=1, D at N>1)")
+    ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-npb", action="store_true", help="skip the full NPB CG run through the ABI")
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed CG iterations of the CPU sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import pkgload
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    n_gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = pkgload.load_package()
+    if not os.path.exists(pkg.lib_path()):
+        pkg.build_all()
+    be = pkg.Backend()
+    if be.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libhip-spmv.so has no CPU fallback")
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    cls = args.cls or ("C" if n_gpus == 1 else "D")
+    t0 = time.time()
+    if n_gpus == 1:
+        m = pkg.npb.NpbMatrix(cls)
+    else:
+        m = pkg.npb.NpbMatrix(cls, part=rank, nparts=n_gpus)
+    log("[rank %d] class %s rows [%d,%d) nnz=%d generated in %.1f s" % (
+        rank, cls, m.row_begin, m.row_end, m.nnz, time.time() - t0))
+
+    # device-resident block, replicated x, local y
+    dm = be.matrix(m.a, m.rowstr, m.colidx, m.rows, device=device, cols_hint=m.na)
+    if args.plan != "auto":
+        name, _, par = args.plan.partition(":")
+        plan = {"stream": pkg.PLAN_STREAM, "vector": pkg.PLAN_VECTOR, "binned": pkg.PLAN_BINNED,
+                "ordered": pkg.PLAN_ORDERED}[name]
+        dm.set_plan(plan, int(par) if par else 0)
+    info = dm.info()
+    x = np.random.default_rng(12345).standard_normal(m.na + 2)  # same on every rank: x is replicated
+    dx = be.malloc(x.nbytes, device)
+    dy = be.malloc(max(m.rows, 1) * 8, device)
+    be.h2d(dx, x, device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dm.spmv_device(dx, dy)
+    be.synchronize(device)
+    barrier()
+    t_start = time.perf_counter()
+    ev_ms = dm.time_device(dx, dy, args.steps)  # K launches, HIP events on the launch stream, synchronised
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    barrier()
+
+    nnz_total = float(m.nnz)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([float(m.nnz)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        nnz_total = float(s.item())
+
+    # sanity: the timed kernel really computed y = A*x (row sums against numpy on a few rows)
+    y = np.empty(m.rows)
+    be.d2h(y, dy, device)
+    for r in (0, m.rows // 2, m.rows - 1):
+        lo, hi = m.rowstr[r] - 1, m.rowstr[r + 1] - 1
+        want = float(np.dot(m.a[lo:hi], x[m.colidx[lo:hi] - 1]))
+        scale = float(np.abs(m.a[lo:hi] * x[m.colidx[lo:hi] - 1]).sum())
+        assert abs(y[r] - want) <= 1e-12 * scale + 1e-300, (r, y[r], want)
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    gflops = 2.0 * nnz_total * args.steps / elapsed / 1e9
+    launch_ms = ev_ms / args.steps
+    achieved = info["algorithmic_bytes"] / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if n_gpus == 1 and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = "%s/%s" % (cls, pkg.abi.PLAN_NAMES[info["plan"]])
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "NPB CG class %s SpMV effective GFLOP/s (FP64 CSR y=A*x, HBM-resident; %% of HBM roofline "
+                  "in `roofline`, NPB CG MOp/s through the ABI in `npb_cg`)" % cls,
+        "value": round(gflops, 3),
+        "unit": "GFLOP/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 6),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": ("NPB3.3.1 CG class %s matrix (own makea restatement, bit-identical to cg.f), "
+                         "na=%d, nnz=%d, one y=A*x per step, A/x/y resident in HBM" % (cls, m.na, int(nnz_total))),
+            "class": cls,
+            "rows": m.na,
+            "nnz": int(nnz_total),
+            "plan": pkg.abi.PLAN_NAMES[info["plan"]],
+            "plan_param": info["plan_param"],
+            "launches_per_step": info["n_launches"],
+            "parallelism": "1 GPU" if n_gpus == 1 else
+                           "block-row partition over %d GPUs (equal nnz), x replicated, no collective" % n_gpus,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "kernel": "k_%s" % pkg.abi.PLAN_NAMES[info["plan"]],
+            "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
+            "launch_us": round(launch_ms * 1e3, 3),
+            "scope": "rank 0's row block" if n_gpus > 1 else "whole matrix",
+        },
+    }
+
+    if rank == 0 and n_gpus == 1 and not args.no_npb:
+        be.reset_stats()
+        res = m.run_cg(be.harness_fn())
+        st = be.stats()
+        line["npb_cg"] = {
+            "class": cls, "mops": round(res["mops"], 2), "time_s": round(res["t_bench"], 4),
+            "time_in_spmv_s": round(res["t_spmv"], 4), "spmv_calls": res["spmv_calls"],
+            "zeta": res["zeta"], "err": res["err"], "verified": bool(res["verified"]),
+            "path": "spmv_harness_ ABI: host x/y every call (PCIe round trip), host vector loops on 1 core",
+            "upload_s": round(st["t_upload"], 4), "init_s": round(st["t_init"], 4),
+        }
+        be.release()
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu:
+        from oracle import oracle as orc  # checker / baseline only
+        if orc.have_reference():
+            cpu, kind = orc.Reference(), "reference"
+        else:
+            cpu, kind = orc.Oracle(), "port"
+        res = m.run_cg(cpu.harness_fn(), niter=args.cpu_iters)
+        calls = res["spmv_calls"]
+        timed_calls = 26 * args.cpu_iters
+        line["cpu_baseline"] = {
+            "value": round(2.0 * m.nnz * timed_calls / res["t_spmv"] / 1e9, 4),
+            "unit": "GFLOP/s",
+            "cores": 1,
+            "kind": kind,
+            "sample": "%d of the 1976 SpMV calls of NPB CG class %s (%d untimed + %d timed CG iterations) on the "
+                      "same matrix through the same spmv_harness_ ABI; %s, gcc -std=c99 -O3, 1 thread of %d" % (
+                          calls, cls, 1, args.cpu_iters,
+                          "reference libspmv/native.c" if kind == "reference" else "oracle/spmv_oracle.c",
+                          os.cpu_count() or 0),
+            "npb_mops": round(res["mops"], 2),
+            "ms_per_spmv": round(res["t_spmv"] / timed_calls * 1e3, 3),
+        }
+
+    dm.close()
+    be.free(dx, device)
+    be.free(dy, device)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

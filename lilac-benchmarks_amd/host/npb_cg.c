@@ -74,7 +74,14 @@ void npb_matrix_free(npb_matrix *m)
     memset(m, 0, sizeof *m);
 }
 
-int npb_makea(char cls, npb_matrix *out)
+/*
+ * Generates rows [*rb,*re) of the class matrix (0-based, half open).  With nparts > 0 the range
+ * is chosen here: part `part` of `nparts` contiguous row blocks of about equal generated-triple
+ * counts (the pre-deduplication proxy for nnz), and returned through rb/re.  Only the triples of
+ * the wanted rows are materialised, so a row block of class D costs 1/nparts of the memory and
+ * sort time; the random stream itself is always run in full (it is O(na * nonzer)).
+ */
+static int makea_rows(char cls, int part, int nparts, int *rb, int *re, npb_matrix *out)
 {
     memset(out, 0, sizeof *out);
     if (npb_class_lookup(cls, &out->cls))
@@ -151,7 +158,37 @@ int npb_makea(char cls, npb_matrix *out)
         }
         start[n] = run;
     }
-    const int64_t ntrip = start[n];
+    /* row range */
+    int r0 = 0, r1 = n;
+    if (nparts > 0) {
+        const int64_t all = start[n];
+        int lo = 0;
+        for (int p = 0; p <= part; ++p) {
+            r0 = lo;
+            if (p == nparts - 1) {
+                lo = n;
+            } else {
+                const int64_t target = all / nparts * (p + 1);
+                while (lo < n && start[lo] < target)
+                    ++lo;
+            }
+            r1 = lo;
+        }
+    } else if (rb && re) {
+        r0 = *rb;
+        r1 = *re;
+        if (r0 < 0 || r1 > n || r0 > r1) {
+            free(arow), free(acol), free(aelt), free(start);
+            return -1;
+        }
+    }
+    if (rb)
+        *rb = r0;
+    if (re)
+        *re = r1;
+    /* offsets relative to the first wanted row */
+    const int64_t trip0 = start[r0];
+    const int64_t ntrip = start[r1] - trip0;
 
     int *tcol = malloc((size_t)(ntrip ? ntrip : 1) * sizeof *tcol);
     double *tval = malloc((size_t)(ntrip ? ntrip : 1) * sizeof *tval);
@@ -159,7 +196,8 @@ int npb_makea(char cls, npb_matrix *out)
     int *ucnt = malloc((size_t)n * sizeof *ucnt);
     if (!tcol || !tval || !pos || !ucnt)
         goto oom1;
-    memcpy(pos, start, (size_t)n * sizeof *pos);
+    for (int j = 0; j < n; ++j)
+        pos[j] = start[j] - trip0;
 
     /* ---- values in generation order (cg.f:818-871) ---- */
     {
@@ -171,6 +209,8 @@ int npb_makea(char cls, npb_matrix *out)
             const int cnt = arow[i];
             for (int e = 0; e < cnt; ++e) {
                 const int j = ic[e]; /* 1-based row */
+                if (j - 1 < r0 || j - 1 >= r1)
+                    continue;
                 const double scale = size * vc[e];
                 int64_t p = pos[j - 1];
                 for (int f = 0; f < cnt; ++f) {
@@ -198,9 +238,9 @@ int npb_makea(char cls, npb_matrix *out)
         double *vtmp = NULL;
         size_t cap = 0;
 #pragma omp for schedule(dynamic, 256)
-        for (int j = 0; j < n; ++j) {
-            const int64_t s = start[j];
-            const size_t len = (size_t)(start[j + 1] - s);
+        for (int j = r0; j < r1; ++j) {
+            const int64_t s = start[j] - trip0;
+            const size_t len = (size_t)(start[j + 1] - start[j]);
             if (len > cap) {
                 free(key), free(vtmp);
                 cap = len * 2 + 64;
@@ -242,18 +282,21 @@ int npb_makea(char cls, npb_matrix *out)
         goto oom1;
 
     /* ---- compact into CSR (cg.f:875-897) ---- */
-    out->rowstr = malloc(((size_t)n + 1) * sizeof *out->rowstr);
+    const int nloc = r1 - r0;
+    out->rowstr = malloc(((size_t)nloc + 1) * sizeof *out->rowstr);
     if (!out->rowstr)
         goto oom1;
     {
         int64_t run = 1;
-        for (int j = 0; j < n; ++j) {
-            out->rowstr[j] = (int)run;
+        for (int j = r0; j < r1; ++j) {
+            out->rowstr[j - r0] = (int)run;
             run += ucnt[j];
         }
-        out->rowstr[n] = (int)run;
+        out->rowstr[nloc] = (int)run;
         out->nnz = run - 1;
     }
+    out->row_begin = r0;
+    out->row_end = r1;
     out->colidx = malloc((size_t)(out->nnz ? out->nnz : 1) * sizeof *out->colidx);
     out->a = malloc((size_t)(out->nnz ? out->nnz : 1) * sizeof *out->a);
     if (!out->colidx || !out->a) {
@@ -261,10 +304,10 @@ int npb_makea(char cls, npb_matrix *out)
         goto oom1;
     }
 #pragma omp parallel for schedule(static)
-    for (int j = 0; j < n; ++j) {
-        const size_t dst = (size_t)out->rowstr[j] - 1;
-        memcpy(out->colidx + dst, tcol + start[j], (size_t)ucnt[j] * sizeof *tcol);
-        memcpy(out->a + dst, tval + start[j], (size_t)ucnt[j] * sizeof *tval);
+    for (int j = r0; j < r1; ++j) {
+        const size_t dst = (size_t)out->rowstr[j - r0] - 1;
+        memcpy(out->colidx + dst, tcol + (start[j] - trip0), (size_t)ucnt[j] * sizeof *tcol);
+        memcpy(out->a + dst, tval + (start[j] - trip0), (size_t)ucnt[j] * sizeof *tval);
     }
     free(tcol), free(tval), free(ucnt), free(start);
     out->t_gen = now_s() - t0;
@@ -275,6 +318,21 @@ oom1:
 oom0:
     free(arow), free(acol), free(aelt), free(start);
     return -2;
+}
+
+int npb_makea(char cls, npb_matrix *out) { return makea_rows(cls, 0, 0, NULL, NULL, out); }
+
+int npb_makea_part(char cls, int part, int nparts, npb_matrix *out)
+{
+    if (nparts < 1 || part < 0 || part >= nparts)
+        return -1;
+    int rb = 0, re = 0;
+    return makea_rows(cls, part, nparts, &rb, &re, out);
+}
+
+int npb_makea_rows(char cls, int row_begin, int row_end, npb_matrix *out)
+{
+    return makea_rows(cls, 0, 0, &row_begin, &row_end, out);
 }
 
 /* ================================ the benchmark ================================== */
@@ -342,8 +400,8 @@ int npb_cg_run(const npb_matrix *m, spmv_harness_fn spmv, int niter_override, in
     memset(out, 0, sizeof *out);
     const int n = m->cls.na;
     const int niter = niter_override > 0 ? niter_override : m->cls.niter;
-    if (niter > NPB_MAX_ITER)
-        return -1;
+    if (niter > NPB_MAX_ITER || m->row_begin != 0 || m->row_end != n)
+        return -1; /* the benchmark loop needs the whole matrix */
     double *x = calloc((size_t)n + 2, sizeof *x), *z = calloc((size_t)n + 2, sizeof *z);
     double *p = calloc((size_t)n + 2, sizeof *p), *q = calloc((size_t)n + 2, sizeof *q);
     double *r = calloc((size_t)n + 2, sizeof *r);

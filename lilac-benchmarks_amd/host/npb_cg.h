@@ -46,6 +46,8 @@ typedef struct npb_matrix {
     int *colidx;   /* [nnz],  1-based */
     double *a;     /* [nnz]           */
     double t_gen;  /* seconds spent generating */
+    int row_begin; /* rows [row_begin,row_end) of the class matrix are held (0-based);          */
+    int row_end;   /* npb_makea gives [0,na); rowstr is local to the block, colidx stays global */
 } npb_matrix;
 
 #define NPB_MAX_ITER 128
@@ -70,6 +72,11 @@ int npb_class_lookup(char name, npb_class *out);
 /* Generates the class matrix.  0 on success; -1 unknown class; -2 out of memory;
  * -3 the class does not fit int32 indices (class E). */
 int npb_makea(char cls, npb_matrix *out);
+/* One of `nparts` contiguous row blocks of about equal weight (the multi-GPU row partition of
+ * SURVEY.md 8(e)); only that block is generated.  Same values, bit for bit, as the rows of npb_makea. */
+int npb_makea_part(char cls, int part, int nparts, npb_matrix *out);
+/* An explicit row range [row_begin,row_end), 0-based. */
+int npb_makea_rows(char cls, int row_begin, int row_end, npb_matrix *out);
 void npb_matrix_free(npb_matrix *m);
 /* Runs the benchmark with `spmv` as the sparse product.  niter_override > 0 shortens the timed loop
  * (verification is then skipped). */

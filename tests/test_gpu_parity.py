@@ -1,0 +1,370 @@
+"""Parity of the HIP backend against the oracle, through the C-ABI, on a real MI355X.
+
+Bars (BASELINE.json north_star):
+  * ORDERED plan: bit-identical to libspmv/native-impl.c:1-25 (same order, no FMA);
+  * integer-valued products (BFS frontiers, bfs/bfs.cc:36-68): bit-exact under every plan;
+  * fast plans reorder a row's sum, so per row |y - y_oracle| <= (len + 2) * eps * sum_j |a_j x_j|
+    (any-order summation bound + one rounding for the FMA), eps = 2^-53 (f64) / 2^-24 (f32);
+  * NPB CG: zeta within 1e-10 relative of the verification value (cg.f:363-368).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import matgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "spmv_golden.npz")
+EPS = {np.dtype(np.float64): 2.0 ** -53, np.dtype(np.float32): 2.0 ** -24}
+
+
+def bits(a):
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def assert_close_rows(y, y_ref, absum, lens, dtype, what=""):
+    tol = (lens.astype(np.float64) + 2.0) * EPS[np.dtype(dtype)] * absum
+    err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
+    bad = np.nonzero(~(err <= tol))[0]
+    assert bad.size == 0, "%s: %d rows off, first row %d: got %r want %r tol %g" % (
+        what, bad.size, bad[0], y[bad[0]], y_ref[bad[0]], tol[bad[0]])
+
+
+def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
+    rows = rs.size - 1
+    lens = np.diff(rs)
+    y_ref = oracle.spmv(a, x, rs, ci, rows)
+    absum = oracle.absum(a, x, rs, ci, rows)
+    m = backend.matrix(a, rs, ci, rows)
+    try:
+        inf = m.info()
+        assert inf["rows"] == rows and inf["nnz"] == rs[-1] - rs[0]
+        assert inf["cols"] == (ci.max() if ci.size else 0)
+        for plan, param in plans:
+            m.set_plan(plan, param)
+            y = m.spmv_host(x)
+            tag = "%s plan=%s/%d" % (what, pkg.abi.PLAN_NAMES[plan], param)
+            if plan == pkg.PLAN_ORDERED:
+                assert np.array_equal(bits(y), bits(y_ref)), tag
+            else:
+                assert_close_rows(y, y_ref, absum, lens, a.dtype, tag)
+    finally:
+        m.close()
+
+
+def all_plans(pkg):
+    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0)]
+    P += [(pkg.PLAN_VECTOR, l) for l in (1, 2, 4, 8, 16, 32, 64)]
+    return P
+
+
+# ------------------------------------------------------------------ the reference's own KAT
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_reference_kat_through_the_abi(backend, dtype):
+    rs, ci, a, x, y = matgen.kat_test_cpp(dtype)
+    out = np.full(12, -1.0, dtype)
+    backend.harness(out, a, x, rs, ci, 12)
+    assert np.array_equal(out, y)  # exact ==, libspmv/test.cpp:53
+
+
+def test_golden_vectors_through_the_abi(backend, oracle):
+    g = np.load(GOLDEN, allow_pickle=False)
+    for name in [str(n) for n in g["names"]]:
+        rs, ci, a, x, y_ref = (g["%s__%s" % (name, k)] for k in ("rowstr", "colidx", "a", "x", "y"))
+        rs, ci, a, x = (np.ascontiguousarray(v) for v in (rs, ci, a, x))
+        rows = rs.size - 1
+        y = np.full(rows, np.nan, a.dtype)
+        backend.harness(y, a, x, rs, ci, rows)
+        if name.startswith(("kat_", "bfs_")):
+            assert np.array_equal(bits(y), bits(y_ref)), name  # integer-valued: exact
+        else:
+            assert_close_rows(y, y_ref, oracle.absum(a, x, rs, ci, rows), np.diff(rs), a.dtype, name)
+
+
+# ------------------------------------------------------------------ every plan, every shape
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_all_plans_on_edge_cases(pkg, backend, oracle, dtype):
+    rng = np.random.default_rng(21)
+    for name, (rs, ci, a, cols) in matgen.edge_cases(dtype).items():
+        x = rng.standard_normal(cols).astype(dtype)
+        check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, all_plans(pkg), name)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_all_plans_on_benchmark_shapes(pkg, backend, oracle, dtype):
+    rng = np.random.default_rng(22)
+    cases = {
+        "npb_like": matgen.npb_like(31, 6000, 240, dtype),
+        "sparsebench_20": matgen.sparsebench_like(32, 20, dtype),
+        "rmat_13": matgen.rmat_graph(33, 13, 8, dtype, values="normal"),
+        "grid_road": matgen.grid2d_graph(90, 70, dtype),
+        "random_ragged": matgen.random_csr(34, 9000, 4000, 30, dtype, empty_frac=0.15, spread=1.0,
+                                           sort_cols=False, distinct=False),
+    }
+    for name, (rs, ci, a) in cases.items():
+        x = rng.standard_normal(int(ci.max())).astype(dtype)
+        check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, all_plans(pkg), name)
+
+
+def test_rowstr_not_starting_at_one(backend, oracle):
+    """native-impl.c indexes a[rowstr[i]-1]: a CSR whose rowstr[0] > 1 skips a prefix of a/colidx."""
+    rs, ci, a = matgen.random_csr(41, 500, 300, 12)
+    x = np.random.default_rng(41).standard_normal(300)
+    shift = 37
+    rs2 = (rs + shift).astype(np.int32)
+    a2 = np.concatenate([np.full(shift, 1e300), a])
+    ci2 = np.concatenate([np.full(shift, 1, np.int32), ci])
+    y = np.empty(500)
+    backend.harness(y, a2, x, rs2, ci2, 500)
+    y_ref = oracle.spmv(a2, x, rs2, ci2, 500)
+    assert_close_rows(y, y_ref, oracle.absum(a2, x, rs2, ci2, 500), np.diff(rs2), np.float64, "rowstr[0]>1")
+
+
+def test_zero_rows_and_all_empty(backend):
+    rs = np.array([1], np.int32)
+    backend.harness(np.zeros(1), np.zeros(1), np.zeros(1), rs, np.zeros(1, np.int32), 0)  # no-op, no crash
+    rs = np.ones(51, np.int32)
+    y = np.full(50, 9.0)
+    backend.harness(y, np.zeros(1), np.ones(4), rs, np.ones(1, np.int32), 50)
+    assert np.all(y == 0.0)  # empty row -> 0.0 (native-impl.c:6,9)
+
+
+# ------------------------------------------------------------------ cache semantics of the ABI path
+def test_cache_and_write_detection(backend, oracle):
+    """libspmv/gpu.c:227-262: pointer-keyed cache, invalidated when the host arrays are written."""
+    rs, ci, a = matgen.npb_like(51, 4000, 120)  # a: ~3.8 MB, many whole pages
+    rows = 4000
+    rng = np.random.default_rng(51)
+    x = rng.standard_normal(rows)
+    y = np.empty(rows)
+    backend.reset_stats()
+    backend.harness(y, a, x, rs, ci, rows)
+    backend.harness(y, a, x, rs, ci, rows)
+    s = backend.stats()
+    assert s["calls"] == 2 and s["uploads"] == 1  # second call hits the cache
+    lens = np.diff(rs)
+
+    def check(tag):
+        y_ref = oracle.spmv(a, x, rs, ci, rows)
+        assert_close_rows(y, y_ref, oracle.absum(a, x, rs, ci, rows), lens, np.float64, tag)
+
+    check("cached")
+    x[:] = rng.standard_normal(rows)  # x changes every call in every caller
+    backend.harness(y, a, x, rs, ci, rows)
+    check("new x")
+    assert backend.stats()["uploads"] == 1
+
+    a[a.size // 2] = 12345.0  # interior page of `a`: faults, handler lets it through
+    backend.harness(y, a, x, rs, ci, rows)
+    check("a edited in place (interior page)")
+    s = backend.stats()
+    assert s["uploads"] == 2 and s["invalidations"] == 1
+
+    a[0] = -777.0  # first (partial or whole) page
+    a[-1] = 555.0  # last page
+    backend.harness(y, a, x, rs, ci, rows)
+    check("a edited at both ends")
+    ci[ci.size // 3] = 1  # colidx edit
+    backend.harness(y, a, x, rs, ci, rows)
+    check("colidx edited")
+    assert backend.stats()["uploads"] == 4
+
+    a2 = a.copy()  # same contents, other pointer: new cache entry, old one still valid
+    backend.harness(y, a2, x, rs, ci, rows)
+    backend.harness(y, a, x, rs, ci, rows)
+    assert backend.stats()["uploads"] == 5
+    check("two cached matrices")
+    backend.release()  # disarms protection; arrays writable again
+    a[1] = 1.0
+
+
+def test_float_and_double_in_one_process(backend, oracle):
+    rs, ci, a = matgen.random_csr(61, 3000, 3000, 20)
+    x = np.random.default_rng(61).standard_normal(3000)
+    af, xf = a.astype(np.float32), x.astype(np.float32)
+    y, yf = np.empty(3000), np.empty(3000, np.float32)
+    for _ in range(2):
+        backend.harness(y, a, x, rs, ci, 3000)
+        backend.harness(yf, af, xf, rs, ci, 3000)
+    lens = np.diff(rs)
+    assert_close_rows(y, oracle.spmv(a, x, rs, ci, 3000), oracle.absum(a, x, rs, ci, 3000), lens, np.float64, "f64")
+    assert_close_rows(yf, oracle.spmv(af, xf, rs, ci, 3000), oracle.absum(af, xf, rs, ci, 3000), lens, np.float32, "f32")
+
+
+# ------------------------------------------------------------------ callers
+def bfs(spmv, rs, ci, a, n, source):
+    """bfs/bfs.cc:36-68 with the SpMV passed in; returns distances and the frontier of every level."""
+    front = np.zeros(n)
+    dist = np.zeros(n)
+    front[source] = 1.0
+    dist[source] = 1.0
+    fronts = []
+    level = 1
+    while True:
+        prod = spmv(front)
+        front = ((prod != 0) & (dist == 0)).astype(np.float64)
+        fronts.append(front.copy())
+        if not front.any():
+            break
+        dist[front != 0] = level + 1
+        level += 1
+    return dist, fronts
+
+
+def test_bfs_frontiers_are_bit_exact(backend, oracle):
+    rs, ci, a = matgen.rmat_graph(71, 14, 8)
+    n = rs.size - 1
+    ybuf = np.empty(n)
+
+    def hip(v):
+        backend.harness(ybuf, a, v, rs, ci, n)
+        return ybuf.copy()
+
+    def ref(v):
+        return oracle.spmv(a, v, rs, ci, n)
+
+    deg = np.diff(rs)
+    for source in (int(np.argmax(deg)), 3, 777):
+        d0, f0 = bfs(ref, rs, ci, a, n, source)
+        d1, f1 = bfs(hip, rs, ci, a, n, source)
+        assert len(f0) == len(f1)
+        for l, (u, v) in enumerate(zip(f0, f1)):
+            assert np.array_equal(bits(u), bits(v)), "frontier of level %d differs" % l
+        assert np.array_equal(bits(d0), bits(d1))
+    # and the raw products (integer counts) are bit-exact too
+    v = (np.random.default_rng(1).random(n) < 0.3).astype(np.float64)
+    assert np.array_equal(bits(hip(v)), bits(ref(v)))
+
+
+@pytest.mark.parametrize("cls", ["S", "A"])
+def test_npb_cg_verifies_through_the_abi(pkg, backend, oracle, cls):
+    m = pkg.npb.NpbMatrix(cls)
+    res = m.run_cg(backend.harness_fn())
+    assert res["spmv_calls"] == 416
+    assert res["verified"] == 1, res
+    assert res["err"] <= 1e-10  # cg.f:363-368
+    ref = m.run_cg(oracle.harness_fn())
+    assert abs(res["zeta"] - ref["zeta"]) / abs(ref["zeta"]) <= 1e-10
+    rn = np.array(res["rnorm_hist"])
+    rn0 = np.array(ref["rnorm_hist"])
+    assert np.all(np.abs(rn - rn0) <= 1e-6 * np.abs(rn0) + 1e-18)
+
+
+# ------------------------------------------------------------------ row partition (multi-GPU path on one GPU)
+def test_row_partitions_reassemble(pkg, backend, oracle):
+    rs, ci, a = matgen.npb_like(81, 5000, 200)
+    rows = 5000
+    x = np.random.default_rng(81).standard_normal(rows)
+    y_ref = oracle.spmv(a, x, rs, ci, rows)
+    absum = oracle.absum(a, x, rs, ci, rows)
+    whole = backend.matrix(a, rs, ci, rows)
+    y_whole = whole.spmv_host(x)
+    for parts in (2, 3, 8):
+        b = backend.partition_rows(rs, rows, parts)
+        y = np.empty(rows)
+        for p in range(parts):
+            m = backend.matrix(a, rs, ci, rows, row_begin=int(b[p]), row_end=int(b[p + 1]), cols_hint=rows)
+            inf = m.info()
+            assert inf["rows"] == b[p + 1] - b[p] and inf["nnz"] == rs[b[p + 1]] - rs[b[p]]
+            y[b[p]:b[p + 1]] = m.spmv_host(x)  # "host gather": each slice lands at its row offset
+            m.close()
+        assert_close_rows(y, y_ref, absum, np.diff(rs), np.float64, "parts=%d" % parts)
+    whole.close()
+    assert_close_rows(y_whole, y_ref, absum, np.diff(rs), np.float64, "whole")
+
+
+def _run_py(code, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    proc = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          env=env, timeout=600)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    return proc.stdout
+
+
+ABI_SCRIPT = """
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, pkgload, matgen
+from oracle.oracle import Oracle
+p = pkgload.load_package(); be = p.Backend(); o = Oracle()
+rs, ci, a = matgen.npb_like(91, 3000, 150)
+rng = np.random.default_rng(91)
+ok = True
+for it in range(3):
+    x = rng.standard_normal(3000); y = np.empty(3000)
+    if it == 2: a[a.size // 2] += 1.0
+    be.harness(y, a, x, rs, ci, 3000)
+    ref = o.spmv(a, x, rs, ci, 3000); ab = o.absum(a, x, rs, ci, 3000)
+    ok &= bool(np.all(np.abs(y - ref) <= (np.diff(rs) + 2) * 2.0**-53 * ab))
+    if %(exact)s: ok &= bool(np.array_equal(y.view(np.uint64), ref.view(np.uint64)))
+s = be.stats(); inf = be.abi_matrix_info()
+print("OK" if ok else "MISMATCH", s["uploads"], s["calls"], inf["plan"], inf["rows"], inf["nnz"])
+"""
+
+
+@pytest.mark.parametrize("env,uploads,exact", [
+    ({"SPMV_HIP_PARTS": "3"}, 2, False),                      # 3 row partitions on one GPU + host gather
+    ({"SPMV_HIP_CACHE": "off"}, 3, False),                    # gpu-slow.c semantics
+    ({"SPMV_HIP_CACHE": "pointer", "SPMV_HIP_PLAN": "stream"}, 1, False),  # gpu-unsafe.c: edit goes unnoticed
+    ({"SPMV_HIP_PLAN": "ordered"}, 2, True),                  # bit-exact mode through the ABI
+    ({"SPMV_HIP_PIN": "register"}, 2, False),
+    ({"SPMV_HIP_PIN": "pageable", "SPMV_HIP_PLAN": "vector:32"}, 2, False),
+])
+def test_abi_policies_in_a_fresh_process(env, uploads, exact):
+    code = ABI_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__), exact="True" if exact else "False")
+    out = _run_py(code, env).split()
+    if env.get("SPMV_HIP_CACHE") == "pointer":
+        assert out[0] == "MISMATCH"  # the unsafe policy misses the in-place edit by design (gpu-unsafe.c:86-127)
+    else:
+        assert out[0] == "OK", out
+    assert int(out[1]) == uploads and int(out[2]) == 3
+    assert (int(out[4]), int(out[5])) == (3000, 0) or int(out[4]) == 3000
+
+
+# ------------------------------------------------------------------ BASELINE's full size, by properties
+def test_class_c_full_size(pkg, backend, oracle):
+    """NPB class C (150000 rows, 36121058 nonzeros): the bench workload itself."""
+    m = pkg.npb.NpbMatrix("C")
+    rows = m.na
+    lens = np.diff(m.rowstr)
+    rng = np.random.default_rng(101)
+    x = rng.standard_normal(rows + 2)
+    z = rng.standard_normal(rows + 2)
+    y_ref = oracle.spmv(m.a, x, m.rowstr, m.colidx, rows)  # one sequential pass: ~0.1 s
+    absum = oracle.absum(m.a, x, m.rowstr, m.colidx, rows)
+    dm = backend.matrix(m.a, m.rowstr, m.colidx, rows)
+    try:
+        inf = dm.info()
+        assert inf["cols"] == rows and inf["nnz"] == 36121058
+        assert inf["algorithmic_bytes"] == 436452700
+        results = {}
+        for plan, param in [(pkg.PLAN_AUTO, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_VECTOR, 64), (pkg.PLAN_VECTOR, 32),
+                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0)]:
+            dm.set_plan(plan, param)
+            y = dm.spmv_host(x)
+            results[(plan, param)] = y
+            if plan == pkg.PLAN_ORDERED:
+                assert np.array_equal(bits(y), bits(y_ref))  # bit-exact at full size
+            else:
+                assert_close_rows(y, y_ref, absum, lens, np.float64, "class C plan %d/%d" % (plan, param))
+        # run-to-run reproducibility (no atomics anywhere)
+        dm.set_plan(pkg.PLAN_AUTO, 0)
+        assert np.array_equal(bits(dm.spmv_host(x)), bits(results[(pkg.PLAN_AUTO, 0)]))
+        # linearity: A(2x - 3z) = 2Ax - 3Az up to rounding
+        yz = dm.spmv_host(z)
+        ylin = dm.spmv_host(2.0 * x - 3.0 * z)
+        absz = oracle.absum(m.a, z, m.rowstr, m.colidx, rows)
+        err = np.abs(ylin - (2.0 * results[(pkg.PLAN_AUTO, 0)] - 3.0 * yz))
+        assert np.all(err <= 4.0 * (lens + 4) * 2.0 ** -53 * (2 * absum + 3 * absz))
+        # the ABI path gives the same bits as the device API (same kernel, same plan)
+        y_abi = np.empty(rows)
+        backend.harness(y_abi, m.a, x, m.rowstr, m.colidx, rows)
+        assert np.array_equal(bits(y_abi), bits(results[(pkg.PLAN_AUTO, 0)]))
+    finally:
+        dm.close()
+        backend.release()
