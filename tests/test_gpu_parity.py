@@ -249,9 +249,8 @@ def test_npb_cg_verifies_through_the_abi(pkg, backend, oracle, cls):
     assert res["err"] <= 1e-10  # cg.f:363-368
     ref = m.run_cg(oracle.harness_fn())
     assert abs(res["zeta"] - ref["zeta"]) / abs(ref["zeta"]) <= 1e-10
-    rn = np.array(res["rnorm_hist"])
-    rn0 = np.array(ref["rnorm_hist"])
-    assert np.all(np.abs(rn - rn0) <= 1e-6 * np.abs(rn0) + 1e-18)
+    # ||x - A z|| is rounding noise at convergence (1e-13 .. 1e-15): only its size is comparable
+    assert max(res["rnorm_hist"]) < 10 * max(ref["rnorm_hist"]) < 1e-10
 
 
 # ------------------------------------------------------------------ row partition (multi-GPU path on one GPU)
@@ -323,7 +322,7 @@ def test_abi_policies_in_a_fresh_process(env, uploads, exact):
     else:
         assert out[0] == "OK", out
     assert int(out[1]) == uploads and int(out[2]) == 3
-    assert (int(out[4]), int(out[5])) == (3000, 0) or int(out[4]) == 3000
+    assert int(out[4]) == 3000
 
 
 # ------------------------------------------------------------------ BASELINE's full size, by properties
