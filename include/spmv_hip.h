@@ -25,7 +25,10 @@ enum {
                                /* libspmv/native-impl.c:1-25                                */
     SPMV_HIP_PLAN_STREAM = 2,  /* row-segment kernel: coalesced a/colidx -> products in LDS  */
     SPMV_HIP_PLAN_VECTOR = 3,  /* L lanes per row straight from global (L = plan_param)      */
-    SPMV_HIP_PLAN_BINNED = 4   /* rows binned by length, one VECTOR launch per bin           */
+    SPMV_HIP_PLAN_BINNED = 4,  /* rows binned by length, one VECTOR launch per bin           */
+    SPMV_HIP_PLAN_TILED = 5    /* column stripes of x held in LDS, one row per lane; sums each  */
+                               /* row stripe by stripe in stored order: bit-identical to the    */
+                               /* reference when a row's columns are sorted                     */
 };
 
 /* Opaque device-resident matrix (CSR block + execution plan) on one GPU. */
@@ -113,7 +116,8 @@ int spmv_hip_memset(int device, void *dst_dev, int value, size_t bytes);
 int spmv_hip_synchronize(int device);
 
 /* Experiment switches for the kernels: key 0 = XCD-contiguous block order (default 1),
- * key 1 = non-temporal loads of a/colidx (default 0).  Not a stable interface. */
+ * key 1 = non-temporal loads of a/colidx (default 0), key 2 = waves per workgroup of the TILED
+ * kernel for matrices created afterwards (8 default, 16).  Not a stable interface. */
 void spmv_hip_set_tuning(int key, int value);
 
 /* ---- ABI-path control ------------------------------------------------------ */

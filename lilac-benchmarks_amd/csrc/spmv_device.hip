@@ -100,6 +100,11 @@ struct spmv_hip_matrix {
     bool have_bins = false;
     int *d_binrows = nullptr;
     int *h_rowstr_local = nullptr; /* rows+1 ints, 1-based copy of the block's rowstr (for replans) */
+    /* TILED (built on demand from the device CSR copy) */
+    bool have_tiled = false;
+    int tiled_rc = 0; /* last build status: 0 ok, -2 not representable */
+    spmv_dev_tiled dt{};
+    size_t tiled_bytes = 0;
 };
 
 extern "C" {
@@ -252,6 +257,13 @@ static void free_plans(spmv_hip_matrix *m)
         (void)hipFree(m->d_partials);
     if (m->d_binrows)
         (void)hipFree(m->d_binrows);
+    if (m->have_tiled) {
+        (void)hipFree((void *)m->dt.wptr);
+        (void)hipFree((void *)m->dt.seg);
+        (void)hipFree((void *)m->dt.col);
+        (void)hipFree((void *)m->dt.val);
+        m->have_tiled = false;
+    }
     m->d_blk = m->d_seg = m->d_lrow = m->d_binrows = nullptr;
     m->d_partials = nullptr;
     spmv_plan_stream_free(&m->sp);
@@ -300,6 +312,105 @@ static int ensure_bins(spmv_hip_matrix *m)
     m->have_bins = true;
     if (upload_ints(&m->d_binrows, m->bp.bin_rows, (size_t)m->bp.bin_off[SPMV_NBINS], &m->device_bytes))
         return -1;
+    return 0;
+}
+
+/*
+ * Builds the TILED layout.  host_a / host_col may be the caller's arrays (creation time, `first`
+ * = 0-based offset of the block's first entry); when they are NULL the device CSR copy is
+ * downloaded instead (plan forced later through spmv_hip_matrix_set_plan).
+ */
+static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_col, int64_t first,
+                        bool auto_choice)
+{
+    if (m->have_tiled)
+        return 0;
+    void *tmp_a = nullptr;
+    int *tmp_c = nullptr;
+    if (!host_a) {
+        tmp_a = malloc((size_t)(m->nnz ? m->nnz : 1) * m->elem);
+        tmp_c = (int *)malloc((size_t)(m->nnz ? m->nnz : 1) * sizeof(int));
+        if (!tmp_a || !tmp_c) {
+            free(tmp_a), free(tmp_c);
+            spmv_set_error("out of host memory for the TILED conversion");
+            return -1;
+        }
+        hipStream_t st = g_dev[m->device].stream;
+        if (m->nnz > 0) {
+            HIPCHK(hipMemcpyAsync(tmp_a, m->d_val, (size_t)m->nnz * m->elem, hipMemcpyDeviceToHost, st),
+                   { free(tmp_a); free(tmp_c); return -1; });
+            HIPCHK(hipMemcpyAsync(tmp_c, m->d_col, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost, st),
+                   { free(tmp_a); free(tmp_c); return -1; });
+        }
+        HIPCHK(hipStreamSynchronize(st), { free(tmp_a); free(tmp_c); return -1; });
+        host_a = tmp_a;
+        host_col = tmp_c;
+        first = 0;
+    }
+    /* h_rowstr_local is the block's own 1-based rowstr; shift the array bases so that its
+     * absolute indices (rowstr[r]-1) land on the block's first entry */
+    const int64_t shift = first - ((int64_t)m->h_rowstr_local[0] - 1);
+    spmv_tiled_host th;
+    int rc = spmv_tiled_build((const char *)host_a + shift * m->elem, m->h_rowstr_local, host_col + shift, 0,
+                              m->rows, m->cols, m->elem, SPMV_TILE_TARGET_BLOCKS, &th);
+    free(tmp_a), free(tmp_c);
+    if (rc == 0 && m->cols < 16) {
+        spmv_tiled_free(&th);
+        rc = -2;
+    }
+    if (rc == 0 && auto_choice && (double)th.nonempty_chunks < 0.5 * (double)th.n_groups * th.S) {
+        spmv_tiled_free(&th);
+        rc = -2; /* columns are local to the rows: x gathers already hit in cache, STREAM is the better plan */
+    }
+    m->tiled_rc = rc;
+    if (rc == -1) {
+        spmv_set_error("out of host memory for the TILED conversion");
+        return -1;
+    }
+    if (rc == -2) {
+        spmv_set_error("matrix not representable in the TILED layout (a chunk exceeds 65535 entries) or not suited to it");
+        return -2;
+    }
+    const size_t nch = (size_t)th.n_groups * th.S;
+    const size_t n_alloc = (size_t)th.n_packed + SPMV_TILE_PAD;
+    void *d_w = nullptr, *d_s = nullptr, *d_c = nullptr, *d_v = nullptr;
+    hipError_t e = hipMalloc(&d_w, (nch + 1) * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_s, (nch * (th.RW + 1) + 1) * sizeof(uint16_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_c, n_alloc * sizeof(uint16_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_v, n_alloc * (size_t)m->elem);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_w, th.wptr, (nch + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_s, th.seg, (nch * (th.RW + 1) + 1) * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        spmv_set_error("TILED upload failed: %s", hipGetErrorString(e));
+        (void)hipFree(d_w), (void)hipFree(d_s), (void)hipFree(d_c), (void)hipFree(d_v);
+        spmv_tiled_free(&th);
+        return -1;
+    }
+    m->dt.wptr = (const int32_t *)d_w;
+    m->dt.seg = (const uint16_t *)d_s;
+    m->dt.col = (const uint16_t *)d_c;
+    m->dt.val = d_v;
+    m->dt.elem = m->elem;
+    m->dt.W = th.W;
+    m->dt.S = th.S;
+    m->dt.WPB = th.WPB;
+    m->dt.RW = th.RW;
+    m->dt.B = th.B;
+    m->dt.rows = m->rows;
+    m->dt.cols = m->cols;
+    m->tiled_bytes = (nch + 1) * 4 + (nch * (th.RW + 1) + 1) * 2 + n_alloc * (2 + (size_t)m->elem);
+    m->device_bytes += m->tiled_bytes;
+    m->have_tiled = true;
+    spmv_tiled_free(&th);
     return 0;
 }
 
@@ -410,7 +521,16 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     }
     HIPCHK(hipStreamSynchronize(st), FAIL());
 
-    spmv_plan_choose(&m->st, elem_size, &m->plan, &m->param);
+    spmv_plan_choose(&m->st, elem_size, m->cols, &m->plan, &m->param);
+    if (m->plan == SPMV_HIP_PLAN_TILED) {
+        int rc = ensure_tiled(m, a, colidx, first, true);
+        if (rc == -2) { /* not representable: the row-segment kernel takes it */
+            m->plan = SPMV_HIP_PLAN_STREAM;
+            m->param = SPMV_STREAM_CAP;
+        } else if (rc) {
+            FAIL();
+        }
+    }
     if (m->plan == SPMV_HIP_PLAN_BINNED && ensure_bins(m))
         FAIL();
 #undef FAIL
@@ -424,7 +544,21 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
     if (hipSetDevice(m->device) != hipSuccess)
         return -1;
     switch (plan) {
-    case SPMV_HIP_PLAN_AUTO: spmv_plan_choose(&m->st, m->elem, &m->plan, &m->param); break;
+    case SPMV_HIP_PLAN_AUTO:
+        spmv_plan_choose(&m->st, m->elem, m->cols, &m->plan, &m->param);
+        if (m->plan == SPMV_HIP_PLAN_TILED && ensure_tiled(m, nullptr, nullptr, 0, true)) {
+            if (m->tiled_rc != -2)
+                return -1;
+            m->plan = SPMV_HIP_PLAN_STREAM;
+            m->param = SPMV_STREAM_CAP;
+        }
+        break;
+    case SPMV_HIP_PLAN_TILED:
+        if (ensure_tiled(m, nullptr, nullptr, 0, false))
+            return -1;
+        m->plan = plan;
+        m->param = m->dt.W;
+        break;
     case SPMV_HIP_PLAN_ORDERED:
         m->plan = plan;
         m->param = 1;
@@ -484,7 +618,7 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     out->min_row_len = m->rows ? m->st.min_len : 0;
     out->max_row_len = m->st.max_len;
     out->mean_row_len = m->st.mean_len;
-    out->n_blocks = m->sp.nblk;
+    out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED ? m->dt.B : m->sp.nblk;
     out->n_long_rows = m->sp.n_long_rows;
     out->n_launches = n_launches(m);
     out->algorithmic_bytes = m->nnz * (int64_t)(m->elem + 4) + ((int64_t)m->rows + 1) * 4 +
@@ -511,6 +645,17 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
     int rc = 0;
     switch (m->plan) {
     case SPMV_HIP_PLAN_ORDERED: rc = spmvk_ordered(&d, x_dev, y_dev, st); break;
+    case SPMV_HIP_PLAN_TILED:
+        if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0) {
+            rc = spmvk_tiled(&m->dt, x_dev, y_dev, st);
+            break;
+        }
+        /* k_tiled stages x with 16-byte loads; a misaligned x goes to the row-segment kernel */
+        rc = spmvk_stream(&d, m->d_blk, m->sp.nblk, x_dev, y_dev, st);
+        if (!rc && m->sp.nseg > 0)
+            rc = spmvk_long(&d, m->d_seg, m->sp.nseg, m->d_lrow, m->sp.nlrow, m->d_partials, x_dev,
+                            y_dev, st);
+        break;
     case SPMV_HIP_PLAN_VECTOR: rc = spmvk_vector(&d, m->param, nullptr, m->rows, x_dev, y_dev, st); break;
     case SPMV_HIP_PLAN_BINNED:
         for (int b = 0; b < SPMV_NBINS && !rc; ++b) {
@@ -566,6 +711,16 @@ int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int
     return rc;
 }
 
-void spmv_hip_set_tuning(int key, int value) { spmvk_set_tuning(key, value); }
+void spmv_hip_set_tuning(int key, int value)
+{
+    if (key == 2)
+        spmv_tiled_set_wpb(value);
+    else if (key == 3)
+        spmv_tiled_set_xbytes(value);
+    else if (key == 4)
+        spmv_tiled_set_blocks(value);
+    else
+        spmvk_set_tuning(key, value);
+}
 
 } // extern "C"

@@ -35,7 +35,7 @@
  *
  * Environment (read once, at the first call):
  *   SPMV_HIP_CACHE   = mprotect (default) | pointer | off
- *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned
+ *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled
  *   SPMV_HIP_DEVICES = number of GPUs to row-partition over (default 1; "all")
  *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
  *                      than devices wraps around -- lets the multi-GPU code path
@@ -374,7 +374,7 @@ static void lazy_init(void)
         } else if (!strcmp(v, "binned"))
             G.plan = SPMV_HIP_PLAN_BINNED;
         else if (strcmp(v, "auto"))
-            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned", v);
+            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled", v);
     }
     G.stats = env_int("SPMV_HIP_STATS", 0);
     G.verbose = env_int("SPMV_HIP_VERBOSE", 0);

@@ -24,6 +24,11 @@ extern "C" {
 #define SPMV_PAD_ELEMS 4096       /* a/colidx are over-allocated by this many entries         */
                                   /* (a = 0, colidx = 1) so aligned vector loads may overrun  */
 #define SPMV_NBINS 4              /* BINNED plan: lanes per row 1 / 4 / 16 / 64               */
+#define SPMV_TILE_LDS_BYTES 32768 /* TILED plan: bytes of x per stripe (two stripes live in LDS)  */
+#define SPMV_TILE_WPB 7           /* TILED plan: compute wavefronts per workgroup (+1 loader)   */
+#define SPMV_TILE_CHUNK 256       /* TILED plan: products staged per wave per pass             */
+#define SPMV_TILE_PAD 4096        /* TILED plan: over-allocation of the packed arrays          */
+#define SPMV_TILE_TARGET_BLOCKS 512 /* two 80-KiB workgroups per CU on 256 CUs                  */
 
 /* ---- host-side row statistics (spmv_plan.c) -------------------------------- */
 typedef struct spmv_row_stats {
@@ -86,8 +91,36 @@ void spmv_plan_bins_free(spmv_bin_plan *p);
 int spmv_plan_bin_of_len(int len);    /* 0..SPMV_NBINS-1 */
 int spmv_plan_bin_lanes(int bin);     /* 1, 4, 16, 64    */
 
+/*
+ * TILED plan (spmv_tiled.c): the block re-laid-out so that a stripe of x can live in LDS.
+ * See the header of spmv_tiled.c for the layout.
+ */
+typedef struct spmv_tiled_host {
+    int elem;          /* 8 / 4                                                        */
+    int W;             /* columns per stripe                                            */
+    int S;             /* stripes                                                       */
+    int WPB;           /* waves per workgroup                                           */
+    int RW;            /* rows per wave (<= 64)                                         */
+    int B;             /* workgroups (row blocks)                                       */
+    int n_groups;      /* B * WPB                                                       */
+    int64_t n_packed;  /* entries incl. alignment pads                                  */
+    int64_t nonempty_chunks; /* (group, stripe) chunks that hold at least one entry          */
+    void *val;         /* T[n_packed + SPMV_TILE_PAD]                                   */
+    uint16_t *col;     /* stripe-local column                                           */
+    int32_t *wptr;     /* [n_groups*S + 1]                                              */
+    uint16_t *seg;     /* [n_groups*S*(RW+1)]                                           */
+} spmv_tiled_host;
+
+int spmv_tiled_geometry(int rows, int cols, int elem_size, int target_blocks, spmv_tiled_host *t);
+int spmv_tiled_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,
+                     int elem_size, int target_blocks, spmv_tiled_host *t);
+void spmv_tiled_free(spmv_tiled_host *t);
+void spmv_tiled_set_wpb(int wpb);       /* experiments: 8 (default) or 16 waves per workgroup */
+void spmv_tiled_set_xbytes(int bytes);  /* experiments: 32768 (default) or 65536 bytes of x per stripe */
+void spmv_tiled_set_blocks(int blocks); /* experiments: workgroups aimed for (0 = default) */
+
 /* Adaptive choice (SPMV_HIP_PLAN_AUTO): fills *plan / *param from the row statistics. */
-void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int *plan, int *param);
+void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *plan, int *param);
 
 /* ---- kernel launchers (spmv_kernels.hip); stream is a hipStream_t ---------- */
 typedef struct spmv_dev_csr {
@@ -105,6 +138,15 @@ int spmvk_vector(const spmv_dev_csr *m, int lanes, const int *row_list, int nrow
 int spmvk_stream(const spmv_dev_csr *m, const int *blk, int nblk, const void *x, void *y, void *stream);
 int spmvk_long(const spmv_dev_csr *m, const int *seg, int nseg, const int *lrow, int nlrow,
                void *partials, const void *x, void *y, void *stream);
+/* TILED: device copies of the spmv_tiled_host arrays; x is the caller's 0-based vector */
+typedef struct spmv_dev_tiled {
+    const int32_t *wptr;
+    const uint16_t *seg;
+    const uint16_t *col;
+    const void *val;
+    int elem, W, S, WPB, RW, B, rows, cols;
+} spmv_dev_tiled;
+int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream);
 /* analysis: max(colidx[0..nnz)) -> *d_out (int, device), must be zeroed first */
 int spmvk_colmax(const int *colidx, int64_t nnz, int *d_out, void *stream);
 /* rowptr0[i] = rowstr[i] - rowstr[0] on device (in place allowed) */

@@ -39,12 +39,15 @@ namespace {
 /* ---- tuning switches (set through spmvk_set_tuning; experiments only) ------- */
 int g_tune_xcd = 1;     /* give each XCD a contiguous range of row blocks        */
 int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx        */
+int g_tune_tile_dbg = 0; /* timing-only ablation bits for k_tiled (results are then wrong) */
+int g_tune_tile_k = 6;  /* register sets (256-entry sub-windows) of k_tiled: 2, 4, 6 or 8 */
 
 /* ---- 16-byte vector types --------------------------------------------------- */
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T> struct Vec16;
 template <> struct Vec16<double> {
@@ -109,6 +112,19 @@ template <typename T, int G> __device__ __forceinline__ T group_sum(T v)
     if constexpr (G >= 64)
         v += dpp_mov<0x143, 0xc>(v); /* row_bcast:31 -> rows 2,3 */
     return v;
+}
+
+/*
+ * Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0), which
+ * would drain the matrix sub-windows a wave of k_tiled keeps in flight across stripe barriers;
+ * here only LDS writes have to be visible to the other waves, so the fences name the local
+ * address space and the wait they lower to is lgkmcnt(0).
+ */
+__device__ __forceinline__ void wg_barrier_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 /* Blocks b, b+8, b+16, ... share an XCD (and its L2): hand every XCD one
@@ -295,6 +311,258 @@ __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
 #undef SPMV_REDUCE_ROWS
 }
 
+
+/* ================================ k_tiled ======================================= */
+/*
+ * TILED plan (layout: spmv_tiled.c).  One workgroup = WPB wavefronts = one row block; it walks
+ * the column stripes in order, keeping the stripe of x in LDS (s_x, 64 KiB), so the per-nonzero
+ * gather is an LDS bank access instead of an L2 line.  Inside a stripe every wave is on its
+ * own: it streams its chunk of packed (value, 16-bit local column) pairs with coalesced
+ * 16-byte loads, 256 entries per pass, parks the products in its private LDS window (s_p) and
+ * then each lane adds up, front to back, the products of the one row it owns.  The accumulator
+ * of a row lives in a register of its lane across all stripes, y is written once, nothing is
+ * atomic, and the order of the additions is the stored order.
+ */
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+/*
+ * One sub-window of packed entries held in registers: 4 entries per lane (their four 16-bit
+ * stripe-local columns packed in two dwords).
+ *
+ * The loads are inline asm on purpose (cdna_hip_programming.md section 5.7, form (ii)): hipcc's
+ * s_waitcnt bookkeeping cannot follow a ring of register sets through the stripe loop and falls
+ * back to vmcnt(0) in front of every use, which drains the look-ahead.  A compute wave of
+ * k_tiled issues no other vector-memory load after its prologue, so the count is ours to keep:
+ * tile_wait<N>() is `s_waitcnt vmcnt(N)` with N = (loads per set) * (R - 1), and it names the
+ * set's registers as read-write operands so that no consumer can be scheduled above it.
+ */
+template <typename T> struct TileRegs;
+template <> struct TileRegs<double> {
+    static constexpr int LOADS = 3;
+    f64x2 va, vb;
+    u32x2 cc;
+    __device__ __forceinline__ double val(int k) const { return k < 2 ? va[k] : vb[k - 2]; }
+    __device__ __forceinline__ unsigned int col(int k) const
+    {
+        const unsigned int pk = cc[k >> 1];
+        return (k & 1) ? (pk >> 16) : (pk & 0xffffu);
+    }
+};
+template <> struct TileRegs<float> {
+    static constexpr int LOADS = 2;
+    f32x4 va;
+    u32x2 cc;
+    __device__ __forceinline__ float val(int k) const { return va[k]; }
+    __device__ __forceinline__ unsigned int col(int k) const
+    {
+        const unsigned int pk = cc[k >> 1];
+        return (k & 1) ? (pk >> 16) : (pk & 0xffffu);
+    }
+};
+
+/* entries [q + 4*lane, +4) of the packed stream; q < 2^31 - padding, so 32-bit offsets */
+__device__ __forceinline__ void tile_load(TileRegs<double> &r, const double *pval, const unsigned short *pcol,
+                                          int q, int lane)
+{
+    const unsigned int e = (unsigned int)q + (unsigned int)lane * 4u;
+    const unsigned int oc = e * 2u, ov = e * 8u;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.cc) : "v"(oc), "s"(pcol) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.va) : "v"(ov), "s"(pval) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(r.vb) : "v"(ov), "s"(pval) : "memory");
+}
+__device__ __forceinline__ void tile_load(TileRegs<float> &r, const float *pval, const unsigned short *pcol,
+                                          int q, int lane)
+{
+    const unsigned int e = (unsigned int)q + (unsigned int)lane * 4u;
+    const unsigned int oc = e * 2u, ov = e * 4u;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.cc) : "v"(oc), "s"(pcol) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.va) : "v"(ov), "s"(pval) : "memory");
+}
+template <int N> __device__ __forceinline__ void tile_wait(TileRegs<double> &r)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.cc), "+v"(r.va), "+v"(r.vb) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void tile_wait(TileRegs<float> &r)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.cc), "+v"(r.va) : "n"(N) : "memory");
+}
+
+template <typename T, int CW, int R, int XT_BYTES>
+__global__ void __launch_bounds__((CW + 1) * 64, 4) k_tiled(const int *__restrict__ wptr,
+                                                            const unsigned short *__restrict__ seg,
+                                                            const unsigned short *__restrict__ pcol,
+                                                            const T *__restrict__ pval,
+                                                            const T *__restrict__ x, T *__restrict__ y,
+                                                            int rows, int cols, int S, int RW, int dbg)
+{
+    using VT = typename Vec16<T>::val_t;
+    constexpr int E = Vec16<T>::E;
+    constexpr int W = XT_BYTES / (int)sizeof(T); /* columns per stripe */
+    constexpr int EPL = 4;                       /* entries per lane per sub-window */
+    constexpr int SUB = 64 * EPL;                /* entries per sub-window = products staged per pass */
+    constexpr int XL = W / (64 * E);             /* 16-byte x loads per loader lane per stripe */
+    constexpr int XB = 16;                       /* ... issued in batches of this many */
+    constexpr int SEGP = 66;                     /* padded row-offset slots per wave (RW + 1 <= 65) */
+    static_assert(XL % XB == 0, "stripe must be a whole number of load batches");
+    static_assert((R + 2) * SUB <= SPMV_TILE_PAD, "look-ahead must stay inside the padding");
+    __shared__ __attribute__((aligned(16))) T s_x[2][W];
+    __shared__ __attribute__((aligned(16))) T s_p[CW][SUB];
+    __shared__ unsigned short s_seg[2][CW][SEGP];
+
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+
+    /* ===================== loader wave: stages x stripes and row offsets ===================== */
+    /*
+     * Wave CW does nothing but copy stripe s+1 of x (and the row offsets of the block's chunks
+     * in that stripe) into the idle LDS buffers while the CW compute waves consume stripe s.
+     * Keeping these loads out of the compute waves matters: vmcnt retires in order, so a
+     * compute wave that mixed them into its own stream could not keep several sub-windows of
+     * matrix data in flight.  No branch around any load: a lane whose 16 bytes would cross the
+     * end of x reads x[0..] instead (those columns are never referenced) and the lane that owns
+     * the <16-byte tail of the last stripe patches it after its own store.
+     */
+    if (w == CW) {
+        const int tail = cols % E;
+        const int tail_pos = (cols - tail) - (S - 1) * W;
+        const bool tail_mine = tail != 0 && ((tail_pos / E) % 64) == lane;
+        const long long gb = (long long)blockIdx.x * CW;
+        auto stage = [&](int s) {
+            const int c0 = s * W;
+            const int nx = (cols - c0) < W ? (cols - c0) : W;
+            const T *xs = x + c0;
+            T *dst = s_x[s & 1];
+            if (!(dbg & 1)) {
+                for (int b0 = 0; b0 < XL; b0 += XB) {
+                    VT v[XB];
+#pragma unroll
+                    for (int k = 0; k < XB; ++k) {
+                        const int i = ((b0 + k) * 64 + lane) * E;
+                        const T *src = (i + E <= nx) ? xs + i : x;
+                        v[k] = *reinterpret_cast<const VT *>(src);
+                    }
+#pragma unroll
+                    for (int k = 0; k < XB; ++k)
+                        *reinterpret_cast<VT *>(&dst[((b0 + k) * 64 + lane) * E]) = v[k];
+                }
+                if (tail_mine && s == S - 1)
+                    for (int j = 0; j < tail; ++j)
+                        dst[tail_pos + j] = x[cols - tail + j];
+            }
+            for (int cw = 0; cw < CW; ++cw) {
+                const unsigned short *sg = seg + ((gb + cw) * S + s) * (RW + 1);
+                for (int r = lane; r <= RW; r += 64)
+                    s_seg[s & 1][cw][r] = sg[r];
+            }
+        };
+        stage(0);
+        wg_barrier_lds();
+        for (int s = 0; s < S; ++s) {
+            if (s + 1 < S)
+                stage(s + 1); /* that buffer was last read in stripe s-1, which every compute wave
+                                 left before the previous barrier */
+            if (!(dbg & 8))
+                wg_barrier_lds();
+        }
+        return;
+    }
+
+    /* ===================== compute waves ===================== */
+    const int g = blockIdx.x * CW + w;
+    const long long ch0 = (long long)g * S;
+    T acc = (T)0;
+    /*
+     * The wave's packed entries are one linear stream starting at wptr[ch0].  It is read in
+     * sub-windows of 256 entries at fixed stream positions, whatever the chunk boundaries;
+     * sub-window j lives in register set j % R and is reloaded with sub-window j + R the moment
+     * it has been consumed, with no register copies, so R-1 sub-windows (2.5 KiB each) are in
+     * flight per wave while one is being worked on, and every load is full.  These are the only
+     * vector-memory loads a compute wave issues, so the counted s_waitcnt in front of each use
+     * leaves exactly the younger R-1 sets outstanding.  The loop nest is sub-window-major; a wave
+     * moves on to the next stripe (barrier) whenever the chunk it is in ends inside the current
+     * sub-window, and every wave of the block meets exactly S barriers.  SPMV_TILE_PAD entries
+     * of padding make the look-ahead past the end of the arrays harmless.
+     */
+    const int P0 = __builtin_amdgcn_readfirstlane(wptr[ch0]); /* hipcc waits for this load here */
+    constexpr int WAITN = TileRegs<T>::LOADS * (R - 1);
+    TileRegs<T> set[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        tile_load(set[r], pval, pcol, P0 + r * SUB, lane);
+
+    const int sl = lane < RW ? lane : RW; /* idle lanes read the total twice: an empty segment */
+    const int sl1 = lane < RW ? lane + 1 : RW;
+    wg_barrier_lds(); /* stripe 0 staged */
+
+    int s = 0;        /* stripe the wave is in */
+    int q = P0;       /* stream position of its chunk */
+    int q_e, n;       /* end of the chunk, entries in it */
+    int abs_s, abs_e; /* stream positions of this lane's row inside the chunk */
+    const T *xt;
+    auto begin_stripe = [&]() {
+        xt = s_x[s & 1];
+        const int o_s = s_seg[s & 1][w][sl], o_e = s_seg[s & 1][w][sl1];
+        n = __builtin_amdgcn_readlane(o_e, RW - 1);
+        abs_s = q + o_s;
+        abs_e = q + o_e;
+        q_e = q + n;
+    };
+    auto end_stripe = [&]() {
+        q += (n + 7) & ~7;
+        if (!(dbg & 8))
+            wg_barrier_lds();
+        ++s;
+    };
+    begin_stripe();
+
+    for (int jj = 0;; jj += R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int sb = P0 + (jj + r) * SUB; /* wave-uniform stream position of set[r] */
+            tile_wait<WAITN>(set[r]);            /* set[r] has landed; the R-1 younger sets stay in flight */
+            for (;;) {
+                if (sb < q_e && sb + SUB > q) {
+                    /* every lane multiplies (entries outside [q, q_e) give products that are never
+                     * read; the & keeps their LDS address inside the stripe) */
+                    T p[EPL];
+#pragma unroll
+                    for (int k = 0; k < EPL; ++k)
+                        p[k] = set[r].val(k) * ((dbg & 4) ? (T)set[r].col(k) : xt[set[r].col(k) & (W - 1)]);
+#pragma unroll
+                    for (int k = 0; k < EPL; ++k)
+                        s_p[w][lane * EPL + k] = p[k];
+                    __builtin_amdgcn_wave_barrier(); /* LDS ops of one wave complete in issue order */
+                    const int lo = (abs_s > sb ? abs_s : sb) - sb;
+                    const int hi = (abs_e < sb + SUB ? abs_e : sb + SUB) - sb;
+                    int k = (dbg & 2) ? hi : lo;
+                    for (; k + 4 <= hi; k += 4) {
+                        const T p0 = s_p[w][k], p1 = s_p[w][k + 1], p2 = s_p[w][k + 2], p3 = s_p[w][k + 3];
+                        acc = acc + p0;
+                        acc = acc + p1;
+                        acc = acc + p2;
+                        acc = acc + p3;
+                    }
+                    for (; k < hi; ++k)
+                        acc = acc + s_p[w][k];
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (q_e > sb + SUB)
+                    break; /* the chunk goes on in the next sub-window */
+                end_stripe();
+                if (s == S)
+                    goto done;
+                begin_stripe();
+            }
+            tile_load(set[r], pval, pcol, sb + R * SUB, lane);
+        }
+    }
+done:
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* retire the look-ahead before the registers die */
+    const int row = g * RW + lane;
+    if (lane < RW && row < rows)
+        y[row] = acc;
+}
+
 /* ================================ k_long ======================================== */
 template <typename T>
 __global__ void __launch_bounds__(SPMV_WG) k_long(const int *__restrict__ seg,
@@ -435,6 +703,10 @@ void spmvk_set_tuning(int key, int value)
         g_tune_xcd = value;
     else if (key == 1)
         g_tune_nt = value;
+    else if (key == 5 && value >= 1 && value <= 8)
+        g_tune_tile_k = value;
+    else if (key == 6)
+        g_tune_tile_dbg = value;
 }
 
 int spmvk_ordered(const spmv_dev_csr *m, const void *x, void *y, void *stream)
@@ -504,6 +776,38 @@ int spmvk_long(const spmv_dev_csr *m, const int *seg, int nseg, const int *lrow,
             hipLaunchKernelGGL(k_long_finish<float>, dim3((nlrow + 63) / 64), dim3(64), 0, st, lrow,
                                (const float *)partials, (float *)y, nlrow);
     }
+    return launch_status();
+}
+
+int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (t->B <= 0)
+        return 0;
+    if (t->WPB != SPMV_TILE_WPB || t->W * t->elem != SPMV_TILE_LDS_BYTES)
+        return (int)hipErrorInvalidValue;
+#define SPMV_LT(T, R)                                                                                  \
+    hipLaunchKernelGGL((k_tiled<T, SPMV_TILE_WPB, R, SPMV_TILE_LDS_BYTES>), dim3(t->B),                \
+                       dim3((SPMV_TILE_WPB + 1) * 64), 0, st, t->wptr, t->seg, t->col,                 \
+                       (const T *)t->val, (const T *)x, (T *)y, t->rows, t->cols, t->S, t->RW,         \
+                       g_tune_tile_dbg)
+#define SPMV_LTK(T)                                                                                    \
+    do {                                                                                               \
+        if (g_tune_tile_k == 2)                                                                        \
+            SPMV_LT(T, 2);                                                                             \
+        else if (g_tune_tile_k == 4)                                                                   \
+            SPMV_LT(T, 4);                                                                             \
+        else if (g_tune_tile_k == 8)                                                                   \
+            SPMV_LT(T, 8);                                                                             \
+        else                                                                                           \
+            SPMV_LT(T, 6);                                                                             \
+    } while (0)
+    if (t->elem == 8)
+        SPMV_LTK(double);
+    else
+        SPMV_LTK(float);
+#undef SPMV_LTK
+#undef SPMV_LT
     return launch_status();
 }
 

@@ -216,21 +216,28 @@ void spmv_plan_bins_free(spmv_bin_plan *p)
 
 /* ---- adaptive choice ------------------------------------------------------------ */
 
-void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int *plan, int *param)
+void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *plan, int *param)
 {
-    (void)elem_size;
     /*
-     * The STREAM kernel reads a/colidx with the same coalesced pattern whatever
-     * the row structure, so it is the default.  Matrices whose rows are all long
-     * enough to fill a wavefront's vector loads several times over go to the
-     * wave-per-row VECTOR kernel, which skips the LDS round trip.
-     * (Thresholds from the measurements recorded in DESIGN.md.)
+     * Default: the STREAM row-segment kernel, which reads a/colidx with the same coalesced
+     * pattern whatever the row structure (5.8 TB/s algorithmic on MI355X when the gathers of x
+     * are local, profiles/r01_kbench2_*.log).
      */
     *plan = SPMV_HIP_PLAN_STREAM;
     *param = SPMV_STREAM_CAP;
-    if (st->rows > 0 && st->min_len >= 96 && st->max_len <= SPMV_STREAM_CAP && st->cv_len < 1.0) {
-        *plan = SPMV_HIP_PLAN_VECTOR;
-        *param = 64;
+    if (st->rows <= 0)
+        return;
+    /*
+     * TILED when x can be walked in a few dozen LDS-sized stripes and every (wave, stripe)
+     * chunk still holds enough nonzeros to stream: then the scattered gathers of x, which bound
+     * STREAM at 1.9 TB/s on NPB class C, become LDS reads.
+     */
+    spmv_tiled_host g;
+    spmv_tiled_geometry(st->rows, cols, elem_size, SPMV_TILE_TARGET_BLOCKS, &g);
+    const double per_chunk = (double)st->nnz / ((double)g.n_groups * (double)g.S);
+    if (st->rows >= 4096 && g.S <= 64 && per_chunk >= 64.0 && cols > g.W / 2) {
+        *plan = SPMV_HIP_PLAN_TILED;
+        *param = g.W;
     }
 }
 

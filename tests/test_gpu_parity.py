@@ -39,16 +39,25 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
     lens = np.diff(rs)
     y_ref = oracle.spmv(a, x, rs, ci, rows)
     absum = oracle.absum(a, x, rs, ci, rows)
+    d = np.diff(ci.astype(np.int64))
+    if rows > 1:
+        d[(rs[1:-1] - rs[0] - 1)[(rs[1:-1] - rs[0] - 1 >= 0) & (rs[1:-1] - rs[0] - 1 < d.size)]] = 1
+    sorted_cols = bool(np.all(d >= 0))  # TILED then adds in the reference's own order: bit-exact
     m = backend.matrix(a, rs, ci, rows)
     try:
         inf = m.info()
         assert inf["rows"] == rows and inf["nnz"] == rs[-1] - rs[0]
         assert inf["cols"] == (ci.max() if ci.size else 0)
         for plan, param in plans:
-            m.set_plan(plan, param)
+            try:
+                m.set_plan(plan, param)
+            except RuntimeError as e:
+                if plan == pkg.PLAN_TILED and "not representable" in str(e):
+                    continue  # a chunk above 65535 entries: AUTO falls back to STREAM for such matrices
+                raise
             y = m.spmv_host(x)
             tag = "%s plan=%s/%d" % (what, pkg.abi.PLAN_NAMES[plan], param)
-            if plan == pkg.PLAN_ORDERED:
+            if plan == pkg.PLAN_ORDERED or (plan == pkg.PLAN_TILED and sorted_cols):
                 assert np.array_equal(bits(y), bits(y_ref)), tag
             else:
                 assert_close_rows(y, y_ref, absum, lens, a.dtype, tag)
@@ -57,7 +66,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
 
 
 def all_plans(pkg):
-    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0)]
+    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0)]
     P += [(pkg.PLAN_VECTOR, l) for l in (1, 2, 4, 8, 16, 32, 64)]
     return P
 
@@ -343,12 +352,13 @@ def test_class_c_full_size(pkg, backend, oracle):
         assert inf["algorithmic_bytes"] == 436452700
         results = {}
         for plan, param in [(pkg.PLAN_AUTO, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_VECTOR, 64), (pkg.PLAN_VECTOR, 32),
-                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0)]:
+                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0), (pkg.PLAN_TILED, 0)]:
             dm.set_plan(plan, param)
             y = dm.spmv_host(x)
             results[(plan, param)] = y
-            if plan == pkg.PLAN_ORDERED:
-                assert np.array_equal(bits(y), bits(y_ref))  # bit-exact at full size
+            if plan in (pkg.PLAN_ORDERED, pkg.PLAN_TILED):
+                # bit-exact at full size (class C rows have sorted columns, cg.f:840-865)
+                assert np.array_equal(bits(y), bits(y_ref)), plan
             else:
                 assert_close_rows(y, y_ref, absum, lens, np.float64, "class C plan %d/%d" % (plan, param))
         # run-to-run reproducibility (no atomics anywhere)

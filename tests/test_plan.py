@@ -146,3 +146,80 @@ def test_partition_degenerate(pkg):
     b = be.partition_rows(rs, 1, 4)
     assert b[0] == 0 and b[-1] == 1 and np.all(np.diff(b) >= 0)
     assert list(be.partition_rows(np.array([1], np.int32), 0, 3)) == [0, 0, 0, 0]
+
+
+class TiledHost(ctypes.Structure):
+    _fields_ = [("elem", ctypes.c_int), ("W", ctypes.c_int), ("S", ctypes.c_int), ("WPB", ctypes.c_int),
+                ("RW", ctypes.c_int), ("B", ctypes.c_int), ("n_groups", ctypes.c_int), ("n_packed", ctypes.c_int64),
+                ("nonempty_chunks", ctypes.c_int64), ("val", ctypes.c_void_p), ("col", ctypes.POINTER(ctypes.c_uint16)),
+                ("wptr", ctypes.POINTER(ctypes.c_int32)), ("seg", ctypes.POINTER(ctypes.c_uint16))]
+
+
+def tiled_emulate(lib, rs, ci, a, x, target_blocks=512):
+    """Runs csrc/spmv_tiled.c and then does on the CPU exactly what k_tiled does with the layout:
+    per row, stripe by stripe, products rounded then added front to back."""
+    rows = rs.size - 1
+    cols = int(ci.max()) if ci.size else 0
+    t = TiledHost()
+    lib.spmv_tiled_build.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(TiledHost)]
+    rc = lib.spmv_tiled_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, rows, cols, a.dtype.itemsize,
+                              target_blocks, ctypes.byref(t))
+    if rc != 0:
+        return rc, None
+    nch = t.n_groups * t.S
+    wptr = np.ctypeslib.as_array(t.wptr, (nch + 1,))
+    seg = np.ctypeslib.as_array(t.seg, (nch * (t.RW + 1),)).reshape(nch, t.RW + 1)
+    col = np.ctypeslib.as_array(t.col, (t.n_packed + 1,))
+    val = np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctypes.c_double if a.dtype == np.float64 else ctypes.c_float)),
+                                (t.n_packed + 1,))
+    assert np.all(wptr % 8 == 0) and np.all(np.diff(wptr) >= 0)
+    assert seg[:, -1].sum() == rs[-1] - rs[0]
+    y = np.zeros(rows, a.dtype)
+    for g in range(t.n_groups):
+        for r in range(t.RW):
+            row = g * t.RW + r
+            if row >= rows:
+                break
+            acc = a.dtype.type(0)
+            for s in range(t.S):
+                ch = g * t.S + s
+                q0 = int(wptr[ch])
+                for k in range(int(seg[ch, r]), int(seg[ch, r + 1])):
+                    p = val[q0 + k] * x[s * t.W + int(col[q0 + k])]
+                    acc = acc + p
+            y[row] = acc
+    geo = dict(W=t.W, S=t.S, RW=t.RW, B=t.B, WPB=t.WPB, n_packed=t.n_packed)
+    lib.spmv_tiled_free.argtypes = [ctypes.POINTER(TiledHost)]
+    lib.spmv_tiled_free(ctypes.byref(t))
+    return 0, (y, geo)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tiled_layout_reproduces_the_reference_order(lib, oracle, dtype):
+    """Sorted columns (every NPB matrix): stripe-by-stripe order == left-to-right order, so the TILED
+    arithmetic is bit-identical to native-impl.c; unsorted columns: equal within the reordering bound."""
+    rng = np.random.default_rng(3)
+    rs, ci, a = matgen.random_csr(8, 700, 40000 if dtype == np.float64 else 70000, 9, dtype, empty_frac=0.1)
+    x = rng.standard_normal(int(ci.max())).astype(dtype)
+    rc, (y, geo) = tiled_emulate(lib, rs, ci, a, x, target_blocks=4)
+    assert rc == 0 and geo["RW"] == -(-700 // (geo["WPB"] * 4)) and geo["W"] * a.dtype.itemsize == 32768
+    assert geo["S"] == -(-int(ci.max()) // geo["W"])
+    y_ref = oracle.spmv(a, x, rs, ci, 700)
+    assert np.array_equal(y.view(np.uint32 if dtype == np.float32 else np.uint64),
+                          y_ref.view(np.uint32 if dtype == np.float32 else np.uint64))
+    rs, ci, a = matgen.random_csr(9, 300, 30000, 12, dtype, sort_cols=False, distinct=False)
+    x = rng.standard_normal(int(ci.max())).astype(dtype)
+    rc, (y, geo) = tiled_emulate(lib, rs, ci, a, x, target_blocks=2)
+    y_ref = oracle.spmv(a, x, rs, ci, 300)
+    eps = 2.0 ** -53 if dtype == np.float64 else 2.0 ** -24
+    assert np.all(np.abs(y.astype(np.float64) - y_ref) <= (np.diff(rs) + 2) * eps * oracle.absum(a, x, rs, ci, 300))
+
+
+def test_tiled_rejects_unrepresentable_chunks(lib):
+    rs, ci, a, cols = matgen.edge_cases()["long_rows_mixed"]
+    big = np.arange(1, 70001, dtype=np.int32)  # one row with 70000 entries inside one 4096-column stripe
+    rs2 = np.array([1, 70001], np.int32)
+    ci2 = ((big - 1) % 4000 + 1).astype(np.int32)
+    rc, _ = tiled_emulate(lib, rs2, ci2, np.ones(70000), np.ones(4000))
+    assert rc == -2

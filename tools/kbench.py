@@ -24,6 +24,13 @@ def build_case(pkg, name, dtype):
         m = pkg.npb.NpbMatrix(name)
         a = m.a if dtype == np.float64 else m.a.astype(np.float32)
         return m.rowstr, m.colidx, a, m  # keep m alive
+    if name == "cband":  # class C row lengths and values, but columns consecutive from the diagonal: local gathers
+        m = pkg.npb.NpbMatrix("C")
+        lens = np.diff(m.rowstr)
+        rowid = np.repeat(np.arange(m.na, dtype=np.int64), lens)
+        k = np.arange(m.nnz, dtype=np.int64) - np.repeat(m.rowstr[:-1].astype(np.int64) - 1, lens)
+        ci = ((rowid + k) % m.na + 1).astype(np.int32)
+        return m.rowstr.copy(), ci, m.a.astype(dtype), None
     if name.startswith("sb"):
         return matgen.sparsebench_like(170, int(name[2:]), dtype) + (None,)
     if name.startswith("rmat"):
@@ -40,11 +47,22 @@ def main():
     ap.add_argument("--cases", default="C,sb100,rmat20,grid2000")
     ap.add_argument("--dtypes", default="f64")
     ap.add_argument("--tunings", default="xcd1nt0,xcd0nt0,xcd1nt1")
+    ap.add_argument("--wpb", type=int, default=7, help="waves per workgroup of the TILED kernel (8|16)")
+    ap.add_argument("--xbytes", type=int, default=32768, help="bytes of x per LDS stripe of the TILED kernel")
+    ap.add_argument("--blocks", type=int, default=0, help="TILED workgroups aimed for (0 = default 512)")
+    ap.add_argument("--tk", type=int, default=6, help="TILED: 256-entry sub-windows per register window")
+    ap.add_argument("--dbg", type=int, default=0, help="TILED timing ablation bits (1 no x stage, 2 no reduce, 4 no gather, 8 no barrier)")
+    ap.add_argument("--plans", default="", help="comma list of plan names to run (default all)")
     args = ap.parse_args()
     pkg = pkgload.load_package()
     be = pkg.Backend()
     assert be.device_count() >= 1
-    plans = [("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
+    be.set_tuning(2, args.wpb)
+    be.set_tuning(3, args.xbytes)
+    be.set_tuning(4, args.blocks)
+    be.set_tuning(5, args.tk)
+    be.set_tuning(6, args.dbg)
+    plans = [("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
              ("vec16", pkg.PLAN_VECTOR, 16), ("vec8", pkg.PLAN_VECTOR, 8), ("vec4", pkg.PLAN_VECTOR, 4),
              ("vec1", pkg.PLAN_VECTOR, 1), ("binned", pkg.PLAN_BINNED, 0), ("ordered", pkg.PLAN_ORDERED, 0),
              ("auto", pkg.PLAN_AUTO, 0)]
@@ -69,9 +87,15 @@ def main():
                 be.set_tuning(0, xcd)
                 be.set_tuning(1, nt)
                 for pname, plan, param in plans:
+                    if args.plans and pname not in args.plans.split(","):
+                        continue
                     if tun != args.tunings.split(",")[0] and pname in ("ordered", "auto", "vec1", "vec4", "vec8"):
                         continue
-                    dm.set_plan(plan, param)
+                    try:
+                        dm.set_plan(plan, param)
+                    except RuntimeError as e:
+                        print("%-10s %-4s %-8s %-9s   unavailable: %s" % (case, dts, pname, tun, e), flush=True)
+                        continue
                     reps = args.reps if pname not in ("ordered", "vec1") else max(3, args.reps // 10)
                     dm.time_device(dx, dy, 3)
                     ms = dm.time_device(dx, dy, reps) / reps
