@@ -25,7 +25,7 @@ extern "C" {
                                   /* (a = 0, colidx = 1) so aligned vector loads may overrun  */
 #define SPMV_NBINS 4              /* BINNED plan: lanes per row 1 / 4 / 16 / 64               */
 #define SPMV_TILE_LDS_BYTES 32768 /* TILED plan: bytes of x per stripe (two stripes live in LDS)  */
-#define SPMV_TILE_WPB 7           /* TILED plan: compute wavefronts per workgroup (+1 loader)   */
+#define SPMV_TILE_WPB 8           /* TILED plan: wavefronts per workgroup (512 threads)        */
 #define SPMV_TILE_CHUNK 256       /* TILED plan: products staged per wave per pass             */
 #define SPMV_TILE_PAD 4096        /* TILED plan: over-allocation of the packed arrays          */
 #define SPMV_TILE_TARGET_BLOCKS 512 /* two 80-KiB workgroups per CU on 256 CUs                  */

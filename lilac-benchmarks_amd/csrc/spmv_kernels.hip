@@ -40,7 +40,7 @@ namespace {
 int g_tune_xcd = 1;     /* give each XCD a contiguous range of row blocks        */
 int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx        */
 int g_tune_tile_dbg = 0; /* timing-only ablation bits for k_tiled (results are then wrong) */
-int g_tune_tile_k = 6;  /* register sets (256-entry sub-windows) of k_tiled: 2, 4, 6 or 8 */
+int g_tune_tile_k = 4;  /* register sets (256-entry sub-windows) of k_tiled: 2, 4, 6 or 8 */
 
 /* ---- 16-byte vector types --------------------------------------------------- */
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -326,173 +326,122 @@ __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-/*
- * One sub-window of packed entries held in registers: 4 entries per lane (their four 16-bit
- * stripe-local columns packed in two dwords).
- *
- * The loads are inline asm on purpose (cdna_hip_programming.md section 5.7, form (ii)): hipcc's
- * s_waitcnt bookkeeping cannot follow a ring of register sets through the stripe loop and falls
- * back to vmcnt(0) in front of every use, which drains the look-ahead.  A compute wave of
- * k_tiled issues no other vector-memory load after its prologue, so the count is ours to keep:
- * tile_wait<N>() is `s_waitcnt vmcnt(N)` with N = (loads per set) * (R - 1), and it names the
- * set's registers as read-write operands so that no consumer can be scheduled above it.
- */
-template <typename T> struct TileRegs;
-template <> struct TileRegs<double> {
-    static constexpr int LOADS = 3;
-    f64x2 va, vb;
-    u32x2 cc;
-    __device__ __forceinline__ double val(int k) const { return k < 2 ? va[k] : vb[k - 2]; }
+/* One sub-window of packed entries held in registers: 4 entries per lane, the four 16-bit
+ * stripe-local columns kept packed in two dwords. */
+template <typename T, int EPL> struct TileRegs {
+    static_assert(EPL == 4, "four entries per lane");
+    T v[4];
+    unsigned int c01, c23;
     __device__ __forceinline__ unsigned int col(int k) const
     {
-        const unsigned int pk = cc[k >> 1];
-        return (k & 1) ? (pk >> 16) : (pk & 0xffffu);
-    }
-};
-template <> struct TileRegs<float> {
-    static constexpr int LOADS = 2;
-    f32x4 va;
-    u32x2 cc;
-    __device__ __forceinline__ float val(int k) const { return va[k]; }
-    __device__ __forceinline__ unsigned int col(int k) const
-    {
-        const unsigned int pk = cc[k >> 1];
+        const unsigned int pk = k < 2 ? c01 : c23;
         return (k & 1) ? (pk >> 16) : (pk & 0xffffu);
     }
 };
 
 /* entries [q + 4*lane, +4) of the packed stream; q < 2^31 - padding, so 32-bit offsets */
-__device__ __forceinline__ void tile_load(TileRegs<double> &r, const double *pval, const unsigned short *pcol,
-                                          int q, int lane)
+template <typename T, int EPL>
+__device__ __forceinline__ void tile_load(TileRegs<T, EPL> &r, const T *__restrict__ pval,
+                                          const unsigned short *__restrict__ pcol, int q, int lane)
 {
-    const unsigned int e = (unsigned int)q + (unsigned int)lane * 4u;
-    const unsigned int oc = e * 2u, ov = e * 8u;
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.cc) : "v"(oc), "s"(pcol) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.va) : "v"(ov), "s"(pval) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(r.vb) : "v"(ov), "s"(pval) : "memory");
-}
-__device__ __forceinline__ void tile_load(TileRegs<float> &r, const float *pval, const unsigned short *pcol,
-                                          int q, int lane)
-{
-    const unsigned int e = (unsigned int)q + (unsigned int)lane * 4u;
-    const unsigned int oc = e * 2u, ov = e * 4u;
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.cc) : "v"(oc), "s"(pcol) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.va) : "v"(ov), "s"(pval) : "memory");
-}
-template <int N> __device__ __forceinline__ void tile_wait(TileRegs<double> &r)
-{
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.cc), "+v"(r.va), "+v"(r.vb) : "n"(N) : "memory");
-}
-template <int N> __device__ __forceinline__ void tile_wait(TileRegs<float> &r)
-{
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.cc), "+v"(r.va) : "n"(N) : "memory");
+    using VT = typename Vec16<T>::val_t;
+    constexpr int E = Vec16<T>::E;
+    const unsigned int e = (unsigned int)q + (unsigned int)lane * EPL;
+    const u32x2 cc = *reinterpret_cast<const u32x2 *>(pcol + e);
+    r.c01 = cc[0];
+    r.c23 = cc[1];
+#pragma unroll
+    for (int k = 0; k < EPL; k += E) {
+        const VT vv = *reinterpret_cast<const VT *>(pval + e + k);
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            r.v[k + i] = vv[i];
+    }
 }
 
-template <typename T, int CW, int R, int XT_BYTES>
-__global__ void __launch_bounds__((CW + 1) * 64, 4) k_tiled(const int *__restrict__ wptr,
-                                                            const unsigned short *__restrict__ seg,
-                                                            const unsigned short *__restrict__ pcol,
-                                                            const T *__restrict__ pval,
-                                                            const T *__restrict__ x, T *__restrict__ y,
-                                                            int rows, int cols, int S, int RW, int dbg)
+template <typename T, int WPB, int R, int XT_BYTES>
+__global__ void __launch_bounds__(WPB * 64, 4) k_tiled(const int *__restrict__ wptr,
+                                                       const unsigned short *__restrict__ seg,
+                                                       const unsigned short *__restrict__ pcol,
+                                                       const T *__restrict__ pval,
+                                                       const T *__restrict__ x, T *__restrict__ y,
+                                                       int rows, int cols, int S, int RW, int dbg)
 {
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E;
     constexpr int W = XT_BYTES / (int)sizeof(T); /* columns per stripe */
     constexpr int EPL = 4;                       /* entries per lane per sub-window */
     constexpr int SUB = 64 * EPL;                /* entries per sub-window = products staged per pass */
-    constexpr int XL = W / (64 * E);             /* 16-byte x loads per loader lane per stripe */
-    constexpr int XB = 16;                       /* ... issued in batches of this many */
-    constexpr int SEGP = 66;                     /* padded row-offset slots per wave (RW + 1 <= 65) */
-    static_assert(XL % XB == 0, "stripe must be a whole number of load batches");
+    constexpr int NT = WPB * 64;
+    constexpr int XV = W / (NT * E);             /* 16-byte x loads per thread per stripe */
+    static_assert(XV * NT * E == W, "stripe must be a whole number of 16-byte loads per thread");
     static_assert((R + 2) * SUB <= SPMV_TILE_PAD, "look-ahead must stay inside the padding");
     __shared__ __attribute__((aligned(16))) T s_x[2][W];
-    __shared__ __attribute__((aligned(16))) T s_p[CW][SUB];
-    __shared__ unsigned short s_seg[2][CW][SEGP];
+    __shared__ __attribute__((aligned(16))) T s_p[WPB][SUB];
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-
-    /* ===================== loader wave: stages x stripes and row offsets ===================== */
-    /*
-     * Wave CW does nothing but copy stripe s+1 of x (and the row offsets of the block's chunks
-     * in that stripe) into the idle LDS buffers while the CW compute waves consume stripe s.
-     * Keeping these loads out of the compute waves matters: vmcnt retires in order, so a
-     * compute wave that mixed them into its own stream could not keep several sub-windows of
-     * matrix data in flight.  No branch around any load: a lane whose 16 bytes would cross the
-     * end of x reads x[0..] instead (those columns are never referenced) and the lane that owns
-     * the <16-byte tail of the last stripe patches it after its own store.
-     */
-    if (w == CW) {
-        const int tail = cols % E;
-        const int tail_pos = (cols - tail) - (S - 1) * W;
-        const bool tail_mine = tail != 0 && ((tail_pos / E) % 64) == lane;
-        const long long gb = (long long)blockIdx.x * CW;
-        auto stage = [&](int s) {
-            const int c0 = s * W;
-            const int nx = (cols - c0) < W ? (cols - c0) : W;
-            const T *xs = x + c0;
-            T *dst = s_x[s & 1];
-            if (!(dbg & 1)) {
-                for (int b0 = 0; b0 < XL; b0 += XB) {
-                    VT v[XB];
-#pragma unroll
-                    for (int k = 0; k < XB; ++k) {
-                        const int i = ((b0 + k) * 64 + lane) * E;
-                        const T *src = (i + E <= nx) ? xs + i : x;
-                        v[k] = *reinterpret_cast<const VT *>(src);
-                    }
-#pragma unroll
-                    for (int k = 0; k < XB; ++k)
-                        *reinterpret_cast<VT *>(&dst[((b0 + k) * 64 + lane) * E]) = v[k];
-                }
-                if (tail_mine && s == S - 1)
-                    for (int j = 0; j < tail; ++j)
-                        dst[tail_pos + j] = x[cols - tail + j];
-            }
-            for (int cw = 0; cw < CW; ++cw) {
-                const unsigned short *sg = seg + ((gb + cw) * S + s) * (RW + 1);
-                for (int r = lane; r <= RW; r += 64)
-                    s_seg[s & 1][cw][r] = sg[r];
-            }
-        };
-        stage(0);
-        wg_barrier_lds();
-        for (int s = 0; s < S; ++s) {
-            if (s + 1 < S)
-                stage(s + 1); /* that buffer was last read in stripe s-1, which every compute wave
-                                 left before the previous barrier */
-            if (!(dbg & 8))
-                wg_barrier_lds();
-        }
-        return;
-    }
-
-    /* ===================== compute waves ===================== */
-    const int g = blockIdx.x * CW + w;
+    const int g = blockIdx.x * WPB + w;
     const long long ch0 = (long long)g * S;
     T acc = (T)0;
+
+    /*
+     * Stripe s+1 of x travels global -> registers while stripe s is being consumed and is
+     * written to the idle LDS buffer when the wave leaves stripe s: one barrier per stripe.  No
+     * branch around any load (a branch makes hipcc wait vmcnt(0) per load): a lane whose 16
+     * bytes would cross the end of x reads x[0..] instead -- its columns are never referenced --
+     * and the <16-byte tail of the last stripe is patched in by the thread that owns that slot.
+     * x must be 16-byte aligned (the launcher checks).
+     */
+    VT xr[XV];
+    auto x_fetch = [&](int s) {
+        const int c0 = s * W;
+        const int nx = (cols - c0) < W ? (cols - c0) : W;
+        const T *xs = x + c0;
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int i = (k * NT + tid) * E;
+            const T *src = (i + E <= nx) ? xs + i : x;
+            xr[k] = *reinterpret_cast<const VT *>(src);
+        }
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < XV; ++k)
+            *reinterpret_cast<VT *>(&s_x[buf][(k * NT + tid) * E]) = xr[k];
+    };
+    const int tail = cols % E;
+    const int tail_pos = (cols - tail) - (S - 1) * W; /* slot of the first tail entry in its stripe */
+    const bool tail_mine = tail != 0 && ((tail_pos / E) % NT) == tid;
+    auto tail_fix = [&](int s) {
+        if (tail_mine && s == S - 1)
+            for (int j = 0; j < tail; ++j)
+                s_x[s & 1][tail_pos + j] = x[cols - tail + j];
+    };
+
     /*
      * The wave's packed entries are one linear stream starting at wptr[ch0].  It is read in
      * sub-windows of 256 entries at fixed stream positions, whatever the chunk boundaries;
      * sub-window j lives in register set j % R and is reloaded with sub-window j + R the moment
-     * it has been consumed, with no register copies, so R-1 sub-windows (2.5 KiB each) are in
-     * flight per wave while one is being worked on, and every load is full.  These are the only
-     * vector-memory loads a compute wave issues, so the counted s_waitcnt in front of each use
-     * leaves exactly the younger R-1 sets outstanding.  The loop nest is sub-window-major; a wave
-     * moves on to the next stripe (barrier) whenever the chunk it is in ends inside the current
-     * sub-window, and every wave of the block meets exactly S barriers.  SPMV_TILE_PAD entries
-     * of padding make the look-ahead past the end of the arrays harmless.
+     * it has been consumed, with no register copies, so every load is full.  The loop nest is
+     * sub-window-major; a wave moves on to the next stripe (x_store, barrier) whenever the chunk
+     * it is in ends inside the current sub-window, and every wave of the block meets exactly S
+     * barriers.  The barrier orders LDS only (wg_barrier_lds), so the look-ahead survives it.
      */
-    const int P0 = __builtin_amdgcn_readfirstlane(wptr[ch0]); /* hipcc waits for this load here */
-    constexpr int WAITN = TileRegs<T>::LOADS * (R - 1);
-    TileRegs<T> set[R];
+    const int P0 = __builtin_amdgcn_readfirstlane(wptr[ch0]);
+    TileRegs<T, EPL> set[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        tile_load(set[r], pval, pcol, P0 + r * SUB, lane);
+        tile_load<T, EPL>(set[r], pval, pcol, P0 + r * SUB, lane);
 
+    /* row-segment offsets of the wave's rows inside the coming chunk, fetched one stripe ahead */
+    const unsigned short *sg = seg + ch0 * (RW + 1);
     const int sl = lane < RW ? lane : RW; /* idle lanes read the total twice: an empty segment */
     const int sl1 = lane < RW ? lane + 1 : RW;
-    wg_barrier_lds(); /* stripe 0 staged */
+    int ns_s = sg[sl], ns_e = sg[sl1];
+    x_fetch(0);
+    x_store(0);
+    tail_fix(0);
+    wg_barrier_lds();
 
     int s = 0;        /* stripe the wave is in */
     int q = P0;       /* stream position of its chunk */
@@ -501,14 +450,25 @@ __global__ void __launch_bounds__((CW + 1) * 64, 4) k_tiled(const int *__restric
     const T *xt;
     auto begin_stripe = [&]() {
         xt = s_x[s & 1];
-        const int o_s = s_seg[s & 1][w][sl], o_e = s_seg[s & 1][w][sl1];
-        n = __builtin_amdgcn_readlane(o_e, RW - 1);
-        abs_s = q + o_s;
-        abs_e = q + o_e;
+        n = __builtin_amdgcn_readlane(ns_e, RW - 1);
+        abs_s = q + ns_s;
+        abs_e = q + ns_e;
         q_e = q + n;
+        if (s + 1 < S) {
+            if (!(dbg & 1))
+                x_fetch(s + 1);
+            sg += RW + 1;
+            ns_s = sg[sl];
+            ns_e = sg[sl1];
+        }
     };
     auto end_stripe = [&]() {
         q += (n + 7) & ~7;
+        if (s + 1 < S && !(dbg & 1)) {
+            x_store((s + 1) & 1); /* that buffer was last read in stripe s-1, which every wave
+                                     left before the previous barrier */
+            tail_fix(s + 1);
+        }
         if (!(dbg & 8))
             wg_barrier_lds();
         ++s;
@@ -519,7 +479,8 @@ __global__ void __launch_bounds__((CW + 1) * 64, 4) k_tiled(const int *__restric
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int sb = P0 + (jj + r) * SUB; /* wave-uniform stream position of set[r] */
-            tile_wait<WAITN>(set[r]);            /* set[r] has landed; the R-1 younger sets stay in flight */
+            const TileRegs<T, EPL> cur = set[r]; /* copy out: one counted wait here, none inside the loop */
+            tile_load<T, EPL>(set[r], pval, pcol, sb + R * SUB, lane);
             for (;;) {
                 if (sb < q_e && sb + SUB > q) {
                     /* every lane multiplies (entries outside [q, q_e) give products that are never
@@ -527,7 +488,7 @@ __global__ void __launch_bounds__((CW + 1) * 64, 4) k_tiled(const int *__restric
                     T p[EPL];
 #pragma unroll
                     for (int k = 0; k < EPL; ++k)
-                        p[k] = set[r].val(k) * ((dbg & 4) ? (T)set[r].col(k) : xt[set[r].col(k) & (W - 1)]);
+                        p[k] = cur.v[k] * ((dbg & 4) ? (T)cur.col(k) : xt[cur.col(k) & (W - 1)]);
 #pragma unroll
                     for (int k = 0; k < EPL; ++k)
                         s_p[w][lane * EPL + k] = p[k];
@@ -553,11 +514,9 @@ __global__ void __launch_bounds__((CW + 1) * 64, 4) k_tiled(const int *__restric
                     goto done;
                 begin_stripe();
             }
-            tile_load(set[r], pval, pcol, sb + R * SUB, lane);
         }
     }
 done:
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* retire the look-ahead before the registers die */
     const int row = g * RW + lane;
     if (lane < RW && row < rows)
         y[row] = acc;
@@ -788,19 +747,19 @@ int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream)
         return (int)hipErrorInvalidValue;
 #define SPMV_LT(T, R)                                                                                  \
     hipLaunchKernelGGL((k_tiled<T, SPMV_TILE_WPB, R, SPMV_TILE_LDS_BYTES>), dim3(t->B),                \
-                       dim3((SPMV_TILE_WPB + 1) * 64), 0, st, t->wptr, t->seg, t->col,                 \
+                       dim3(SPMV_TILE_WPB * 64), 0, st, t->wptr, t->seg, t->col,                       \
                        (const T *)t->val, (const T *)x, (T *)y, t->rows, t->cols, t->S, t->RW,         \
                        g_tune_tile_dbg)
 #define SPMV_LTK(T)                                                                                    \
     do {                                                                                               \
         if (g_tune_tile_k == 2)                                                                        \
             SPMV_LT(T, 2);                                                                             \
-        else if (g_tune_tile_k == 4)                                                                   \
-            SPMV_LT(T, 4);                                                                             \
+        else if (g_tune_tile_k == 6)                                                                   \
+            SPMV_LT(T, 6);                                                                             \
         else if (g_tune_tile_k == 8)                                                                   \
             SPMV_LT(T, 8);                                                                             \
         else                                                                                           \
-            SPMV_LT(T, 6);                                                                             \
+            SPMV_LT(T, 4);                                                                             \
     } while (0)
     if (t->elem == 8)
         SPMV_LTK(double);

@@ -14,8 +14,7 @@
  *
  *   stripes   S = ceil(cols / W) column ranges of W columns (W * sizeof(T) = 32 KiB of LDS,
  *             double-buffered by the kernel)
- *   blocks    B = ceil(rows / (WPB * RW)) row blocks; a block is one workgroup of WPB compute waves
- *             (plus one loader wave that owns no rows),
+ *   blocks    B = ceil(rows / (WPB * RW)) row blocks; a block is one workgroup of WPB waves,
  *             wave w of block b owns the RW (<= 64) consecutive rows
  *             [(b*WPB + w)*RW, +RW): one row per lane, accumulator in a register
  *   chunk     (g, s) = the nonzeros of wave-group g = b*WPB + w that fall in stripe s,

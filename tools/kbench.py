@@ -47,10 +47,10 @@ def main():
     ap.add_argument("--cases", default="C,sb100,rmat20,grid2000")
     ap.add_argument("--dtypes", default="f64")
     ap.add_argument("--tunings", default="xcd1nt0,xcd0nt0,xcd1nt1")
-    ap.add_argument("--wpb", type=int, default=7, help="waves per workgroup of the TILED kernel (8|16)")
+    ap.add_argument("--wpb", type=int, default=8, help="waves per workgroup of the TILED kernel (8|16)")
     ap.add_argument("--xbytes", type=int, default=32768, help="bytes of x per LDS stripe of the TILED kernel")
     ap.add_argument("--blocks", type=int, default=0, help="TILED workgroups aimed for (0 = default 512)")
-    ap.add_argument("--tk", type=int, default=6, help="TILED: 256-entry sub-windows per register window")
+    ap.add_argument("--tk", type=int, default=4, help="TILED: 256-entry sub-windows per register window")
     ap.add_argument("--dbg", type=int, default=0, help="TILED timing ablation bits (1 no x stage, 2 no reduce, 4 no gather, 8 no barrier)")
     ap.add_argument("--plans", default="", help="comma list of plan names to run (default all)")
     args = ap.parse_args()
