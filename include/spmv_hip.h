@@ -26,9 +26,11 @@ enum {
     SPMV_HIP_PLAN_STREAM = 2,  /* row-segment kernel: coalesced a/colidx -> products in LDS  */
     SPMV_HIP_PLAN_VECTOR = 3,  /* L lanes per row straight from global (L = plan_param)      */
     SPMV_HIP_PLAN_BINNED = 4,  /* rows binned by length, one VECTOR launch per bin           */
-    SPMV_HIP_PLAN_TILED = 5    /* column stripes of x held in LDS, one row per lane; sums each  */
+    SPMV_HIP_PLAN_TILED = 5,   /* column stripes of x held in LDS, one row per lane; sums each  */
                                /* row stripe by stripe in stored order: bit-identical to the    */
                                /* reference when a row's columns are sorted                     */
+    SPMV_HIP_PLAN_STRIPED = 6  /* 2-D: a workgroup keeps one stripe of x in LDS for its whole    */
+                               /* life; per-(stripe,row) partial sums added in stripe order      */
 };
 
 /* Opaque device-resident matrix (CSR block + execution plan) on one GPU. */

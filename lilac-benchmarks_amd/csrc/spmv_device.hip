@@ -105,6 +105,10 @@ struct spmv_hip_matrix {
     int tiled_rc = 0; /* last build status: 0 ok, -2 not representable */
     spmv_dev_tiled dt{};
     size_t tiled_bytes = 0;
+    /* STRIPED (built on demand) */
+    bool have_striped = false;
+    int striped_rc = 0;
+    spmv_dev_striped ds{};
 };
 
 extern "C" {
@@ -257,6 +261,14 @@ static void free_plans(spmv_hip_matrix *m)
         (void)hipFree(m->d_partials);
     if (m->d_binrows)
         (void)hipFree(m->d_binrows);
+    if (m->have_striped) {
+        (void)hipFree((void *)m->ds.wptr);
+        (void)hipFree((void *)m->ds.wrow);
+        (void)hipFree((void *)m->ds.col);
+        (void)hipFree((void *)m->ds.val);
+        (void)hipFree(m->ds.partial);
+        m->have_striped = false;
+    }
     if (m->have_tiled) {
         (void)hipFree((void *)m->dt.wptr);
         (void)hipFree((void *)m->dt.seg);
@@ -414,6 +426,106 @@ static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_
     return 0;
 }
 
+/* geometry knobs of the STRIPED plan (experiments through spmv_hip_set_tuning keys 7..9) */
+static int g_stripe_xbytes = SPMV_STRIPE_XBYTES, g_stripe_wpb = SPMV_STRIPE_WPB, g_stripe_wgs = SPMV_STRIPE_TARGET_WGS,
+           g_stripe_epl = SPMV_STRIPE_EPL;
+
+/* Builds the STRIPED layout; same conventions as ensure_tiled. */
+static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *host_col, int64_t first,
+                          bool auto_choice)
+{
+    if (m->have_striped)
+        return 0;
+    void *tmp_a = nullptr;
+    int *tmp_c = nullptr;
+    if (!host_a) {
+        tmp_a = malloc((size_t)(m->nnz ? m->nnz : 1) * m->elem);
+        tmp_c = (int *)malloc((size_t)(m->nnz ? m->nnz : 1) * sizeof(int));
+        if (!tmp_a || !tmp_c) {
+            free(tmp_a), free(tmp_c);
+            spmv_set_error("out of host memory for the STRIPED conversion");
+            return -1;
+        }
+        hipStream_t st = g_dev[m->device].stream;
+        if (m->nnz > 0) {
+            HIPCHK(hipMemcpyAsync(tmp_a, m->d_val, (size_t)m->nnz * m->elem, hipMemcpyDeviceToHost, st),
+                   { free(tmp_a); free(tmp_c); return -1; });
+            HIPCHK(hipMemcpyAsync(tmp_c, m->d_col, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost, st),
+                   { free(tmp_a); free(tmp_c); return -1; });
+        }
+        HIPCHK(hipStreamSynchronize(st), { free(tmp_a); free(tmp_c); return -1; });
+        host_a = tmp_a;
+        host_col = tmp_c;
+        first = 0;
+    }
+    const int64_t shift = first - ((int64_t)m->h_rowstr_local[0] - 1);
+    spmv_striped_host th;
+    int rc = m->cols < 16 ? -2
+                          : spmv_striped_build((const char *)host_a + shift * m->elem, m->h_rowstr_local,
+                                               host_col + shift, 0, m->rows, m->cols, m->elem, g_stripe_xbytes,
+                                               g_stripe_wpb, g_stripe_wgs, g_stripe_epl, &th);
+    free(tmp_a), free(tmp_c);
+    if (rc == 0 && auto_choice && th.n_dummies * 2 > (int64_t)th.S * m->rows) {
+        /* most (row, stripe) pairs are empty: the columns are local to the rows, x gathers already
+         * hit in cache and the STREAM kernel is the better plan (measured: 73 us vs 133 us) */
+        spmv_striped_free(&th);
+        rc = -2;
+    }
+    m->striped_rc = rc;
+    if (rc == -1) {
+        spmv_set_error("out of host memory for the STRIPED conversion");
+        return -1;
+    }
+    if (rc == -2) {
+        spmv_set_error("matrix not representable in the STRIPED layout or not suited to it");
+        return -2;
+    }
+    const size_t nw = (size_t)th.n_waves;
+    const size_t n_alloc = (size_t)th.n_packed + SPMV_TILE_PAD;
+    const size_t pbytes = (size_t)th.S * (size_t)m->rows * (size_t)m->elem;
+    void *d_w = nullptr, *d_r = nullptr, *d_c = nullptr, *d_v = nullptr, *d_p = nullptr;
+    hipError_t e = hipMalloc(&d_w, (nw + 1) * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_r, (nw + 1) * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_c, n_alloc * sizeof(uint16_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_v, n_alloc * (size_t)m->elem);
+    if (e == hipSuccess)
+        e = hipMalloc(&d_p, pbytes + 64);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_w, th.wptr, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_r, th.wrow, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        spmv_set_error("STRIPED upload failed: %s", hipGetErrorString(e));
+        (void)hipFree(d_w), (void)hipFree(d_r), (void)hipFree(d_c), (void)hipFree(d_v), (void)hipFree(d_p);
+        spmv_striped_free(&th);
+        return -1;
+    }
+    m->ds.wptr = (const int32_t *)d_w;
+    m->ds.wrow = (const int32_t *)d_r;
+    m->ds.col = (const uint16_t *)d_c;
+    m->ds.val = d_v;
+    m->ds.partial = d_p;
+    m->ds.elem = m->elem;
+    m->ds.W = th.W;
+    m->ds.S = th.S;
+    m->ds.WPB = th.WPB;
+    m->ds.B = th.B;
+    m->ds.EPL = th.EPL;
+    m->ds.rows = m->rows;
+    m->ds.cols = m->cols;
+    m->device_bytes += (nw + 1) * 8 + n_alloc * (2 + (size_t)m->elem) + pbytes;
+    m->have_striped = true;
+    spmv_striped_free(&th);
+    return 0;
+}
+
 spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const int *colidx, int rows,
                                         int elem_size, int device, int row_begin, int row_end,
                                         int cols_hint)
@@ -531,6 +643,15 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
             FAIL();
         }
     }
+    if (m->plan == SPMV_HIP_PLAN_STRIPED) {
+        int rc = ensure_striped(m, a, colidx, first, true);
+        if (rc == -2) {
+            m->plan = SPMV_HIP_PLAN_STREAM;
+            m->param = SPMV_STREAM_CAP;
+        } else if (rc) {
+            FAIL();
+        }
+    }
     if (m->plan == SPMV_HIP_PLAN_BINNED && ensure_bins(m))
         FAIL();
 #undef FAIL
@@ -552,12 +673,24 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
         }
+        if (m->plan == SPMV_HIP_PLAN_STRIPED && ensure_striped(m, nullptr, nullptr, 0, true)) {
+            if (m->striped_rc != -2)
+                return -1;
+            m->plan = SPMV_HIP_PLAN_STREAM;
+            m->param = SPMV_STREAM_CAP;
+        }
         break;
     case SPMV_HIP_PLAN_TILED:
         if (ensure_tiled(m, nullptr, nullptr, 0, false))
             return -1;
         m->plan = plan;
         m->param = m->dt.W;
+        break;
+    case SPMV_HIP_PLAN_STRIPED:
+        if (ensure_striped(m, nullptr, nullptr, 0, false))
+            return -1;
+        m->plan = plan;
+        m->param = m->ds.W;
         break;
     case SPMV_HIP_PLAN_ORDERED:
         m->plan = plan;
@@ -592,6 +725,7 @@ static int n_launches(const spmv_hip_matrix *m)
 {
     int longk = m->sp.nseg > 0 ? 1 + (m->sp.nlrow > 0) : 0;
     switch (m->plan) {
+    case SPMV_HIP_PLAN_STRIPED: return 2;
     case SPMV_HIP_PLAN_STREAM: return 1 + longk;
     case SPMV_HIP_PLAN_BINNED: {
         int n = longk;
@@ -618,7 +752,9 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     out->min_row_len = m->rows ? m->st.min_len : 0;
     out->max_row_len = m->st.max_len;
     out->mean_row_len = m->st.mean_len;
-    out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED ? m->dt.B : m->sp.nblk;
+    out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED     ? m->dt.B
+                    : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.S * m->ds.B
+                                                       : m->sp.nblk;
     out->n_long_rows = m->sp.n_long_rows;
     out->n_launches = n_launches(m);
     out->algorithmic_bytes = m->nnz * (int64_t)(m->elem + 4) + ((int64_t)m->rows + 1) * 4 +
@@ -645,9 +781,11 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
     int rc = 0;
     switch (m->plan) {
     case SPMV_HIP_PLAN_ORDERED: rc = spmvk_ordered(&d, x_dev, y_dev, st); break;
+    case SPMV_HIP_PLAN_STRIPED:
     case SPMV_HIP_PLAN_TILED:
         if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0) {
-            rc = spmvk_tiled(&m->dt, x_dev, y_dev, st);
+            rc = m->plan == SPMV_HIP_PLAN_TILED ? spmvk_tiled(&m->dt, x_dev, y_dev, st)
+                                                : spmvk_striped(&m->ds, x_dev, y_dev, st);
             break;
         }
         /* k_tiled stages x with 16-byte loads; a misaligned x goes to the row-segment kernel */
@@ -719,6 +857,14 @@ void spmv_hip_set_tuning(int key, int value)
         spmv_tiled_set_xbytes(value);
     else if (key == 4)
         spmv_tiled_set_blocks(value);
+    else if (key == 7 && (value == 65536 || value == 131072))
+        g_stripe_xbytes = value;
+    else if (key == 8 && (value == 8 || value == 16))
+        g_stripe_wpb = value;
+    else if (key == 9 && value > 0)
+        g_stripe_wgs = value;
+    else if (key == 10 && (value == 4 || value == 8))
+        g_stripe_epl = value;
     else
         spmvk_set_tuning(key, value);
 }

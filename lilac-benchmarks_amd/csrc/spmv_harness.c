@@ -34,8 +34,15 @@
  *          GPU the first call aborts.
  *
  * Environment (read once, at the first call):
- *   SPMV_HIP_CACHE   = mprotect (default) | pointer | off
- *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled
+ *   SPMV_HIP_CACHE   = mprotect (default) | compare | pointer | off
+ *                      mprotect: write detection by page protection for arrays of >= 64 whole
+ *                      pages, byte comparison against a saved copy for smaller ones and for the
+ *                      partial first/last pages.  Like libspmv/gpu.c it leaves the caller's matrix
+ *                      pages read-only while the copy is cached: a caller that FREES a cached
+ *                      matrix should call spmv_hip_release() first (or use compare/pointer/off),
+ *                      because recycled heap pages would still be read-only for system calls.
+ *                      compare: no page protection, every call compares the arrays byte for byte.
+ *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped
  *   SPMV_HIP_DEVICES = number of GPUs to row-partition over (default 1; "all")
  *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
  *                      than devices wraps around -- lets the multi-GPU code path
@@ -63,7 +70,8 @@
 #define MAX_PARTS 16
 #define MAX_REG 32
 
-enum { CACHE_MPROTECT = 0, CACHE_POINTER = 1, CACHE_OFF = 2 };
+enum { CACHE_MPROTECT = 0, CACHE_POINTER = 1, CACHE_OFF = 2, CACHE_COMPARE = 3 };
+#define MIN_PROTECT_PAGES 64 /* arrays with fewer whole pages are compared byte for byte instead */
 enum { PIN_STAGING = 0, PIN_REGISTER = 1, PIN_PAGEABLE = 2 };
 
 /* one guarded host array: [p, p+bytes) */
@@ -213,6 +221,18 @@ static int guard_arm(guard *g, const void *p, size_t bytes, int protect)
     uintptr_t b = (uintptr_t)p, e = b + bytes;
     uintptr_t lo = (b + pg - 1) / pg * pg; /* first page boundary >= b */
     uintptr_t hi = e / pg * pg;            /* last page boundary  <= e */
+    if (protect == 2 || (protect && hi < lo + (uintptr_t)MIN_PROTECT_PAGES * pg)) {
+        /* CACHE_COMPARE, or a small array: keep a full copy and compare it on every call.  Small
+         * arrays usually live in the malloc heap; leaving heap pages read-only after the caller
+         * frees them would make a later read(2) into the recycled memory fail with EFAULT. */
+        g->head_n = bytes;
+        g->head = (unsigned char *)malloc(bytes);
+        if (!g->head)
+            return -1;
+        memcpy(g->head, p, bytes);
+        g->lo = g->hi = (char *)e;
+        return 0;
+    }
     if (!protect || hi <= lo) {
         /* no whole page inside: the array is covered by saved copies only */
         lo = hi = e;
@@ -349,8 +369,10 @@ static void lazy_init(void)
             G.cache = CACHE_POINTER;
         else if (!strcmp(v, "off") || !strcmp(v, "slow"))
             G.cache = CACHE_OFF;
+        else if (!strcmp(v, "compare"))
+            G.cache = CACHE_COMPARE;
         else if (strcmp(v, "mprotect"))
-            die("SPMV_HIP_CACHE=%s: expected mprotect|pointer|off", v);
+            die("SPMV_HIP_CACHE=%s: expected mprotect|compare|pointer|off", v);
     }
     G.pin = PIN_STAGING;
     if ((v = getenv("SPMV_HIP_PIN"))) {
@@ -374,7 +396,7 @@ static void lazy_init(void)
         } else if (!strcmp(v, "binned"))
             G.plan = SPMV_HIP_PLAN_BINNED;
         else if (strcmp(v, "auto"))
-            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled", v);
+            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped", v);
     }
     G.stats = env_int("SPMV_HIP_STATS", 0);
     G.verbose = env_int("SPMV_HIP_VERBOSE", 0);
@@ -476,15 +498,15 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
 
     /* arm write detection AFTER the upload (the copies read the arrays) */
     if (G.cache != CACHE_OFF) {
-        const int protect = (G.cache == CACHE_MPROTECT);
+        const int protect = G.cache == CACHE_MPROTECT ? 1 : (G.cache == CACHE_COMPARE ? 2 : 0);
         const size_t off = (size_t)(rowstr[0] - 1);
         const void *ptrs[3] = {(const char *)a + off * elem, rowstr, colidx + off};
         const size_t lens[3] = {(size_t)nnz * elem, ((size_t)rows + 1) * sizeof(int),
                                 (size_t)nnz * sizeof(int)};
-        if (protect)
+        if (protect == 1)
             install_handler();
         int ok = 1;
-        sl->armed = protect ? 1 : 0; /* set before protecting: a fault may come at once */
+        sl->armed = protect == 1 ? 1 : 0; /* set before protecting: a fault may come at once */
         for (int k = 0; k < 3 && ok; ++k) {
             int rc = guard_arm(&sl->g[k], ptrs[k], lens[k], protect);
             if (rc == -1)
@@ -575,7 +597,7 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
     slot *sl = slot_find(a, rowstr, colidx, rows, nnz, elem);
     if (sl) {
         int stale = (G.cache == CACHE_OFF) || sl->dirty || sl->first != rowstr[0];
-        if (!stale && G.cache == CACHE_MPROTECT)
+        if (!stale && (G.cache == CACHE_MPROTECT || G.cache == CACHE_COMPARE))
             for (int k = 0; k < 3 && !stale; ++k)
                 stale = guard_fragments_changed(&sl->g[k]);
         if (stale) {

@@ -119,6 +119,30 @@ void spmv_tiled_set_wpb(int wpb);       /* experiments: 8 (default) or 16 waves 
 void spmv_tiled_set_xbytes(int bytes);  /* experiments: 32768 (default) or 65536 bytes of x per stripe */
 void spmv_tiled_set_blocks(int blocks); /* experiments: workgroups aimed for (0 = default) */
 
+/*
+ * STRIPED plan (spmv_striped.c): 2-D decomposition, one column stripe of x per workgroup for its
+ * whole life, row ends flagged in bit 15 of the 16-bit column, partial sums per (stripe, row).
+ */
+#define SPMV_STRIPE_XBYTES 131072  /* bytes of x per stripe (single LDS buffer, one workgroup/CU) */
+#define SPMV_STRIPE_WPB 16         /* waves per workgroup                                        */
+#define SPMV_STRIPE_TARGET_WGS 256 /* workgroups aimed for: one 160-KiB workgroup per CU          */
+#define SPMV_STRIPE_EPL 4          /* entries per lane per sub-window                            */
+typedef struct spmv_striped_host {
+    int elem, W, S, WPB, B, n_waves;
+    int EPL;       /* entries per lane per sub-window (4 or 8); a sub-window = 64*EPL entries */
+    int64_t n_packed, n_dummies;
+    void *val;
+    uint16_t *col;
+    int32_t *wptr; /* [n_waves + 1] */
+    int32_t *wrow; /* [n_waves + 1] first row of each wave's range */
+} spmv_striped_host;
+
+void spmv_striped_geometry(int rows, int cols, int elem_size, int xbytes, int wpb, int target_wgs, int epl,
+                           spmv_striped_host *t);
+int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,
+                       int elem_size, int xbytes, int wpb, int target_wgs, int epl, spmv_striped_host *t);
+void spmv_striped_free(spmv_striped_host *t);
+
 /* Adaptive choice (SPMV_HIP_PLAN_AUTO): fills *plan / *param from the row statistics. */
 void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *plan, int *param);
 
@@ -147,6 +171,15 @@ typedef struct spmv_dev_tiled {
     int elem, W, S, WPB, RW, B, rows, cols;
 } spmv_dev_tiled;
 int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream);
+typedef struct spmv_dev_striped {
+    const int32_t *wptr;
+    const int32_t *wrow;
+    const uint16_t *col;
+    const void *val;
+    void *partial; /* T[S * rows] */
+    int elem, W, S, WPB, B, EPL, rows, cols;
+} spmv_dev_striped;
+int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream);
 /* analysis: max(colidx[0..nnz)) -> *d_out (int, device), must be zeroed first */
 int spmvk_colmax(const int *colidx, int64_t nnz, int *d_out, void *stream);
 /* rowptr0[i] = rowstr[i] - rowstr[0] on device (in place allowed) */

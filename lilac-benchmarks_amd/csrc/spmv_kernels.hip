@@ -40,7 +40,7 @@ namespace {
 int g_tune_xcd = 1;     /* give each XCD a contiguous range of row blocks        */
 int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx        */
 int g_tune_tile_dbg = 0; /* timing-only ablation bits for k_tiled (results are then wrong) */
-int g_tune_tile_k = 4;  /* register sets (256-entry sub-windows) of k_tiled: 2, 4, 6 or 8 */
+int g_tune_tile_k = 0;  /* register sets of k_tiled (2,4,6,8; default 4) / k_striped (2,3,4; default 2) */
 
 /* ---- 16-byte vector types --------------------------------------------------- */
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -522,6 +522,254 @@ done:
         y[row] = acc;
 }
 
+
+/* ================================ k_striped ===================================== */
+/*
+ * STRIPED plan (layout: spmv_striped.c).  Workgroup = (stripe s, row range b): it copies its
+ * stripe of x into LDS once, one barrier, and from then on every wave is on its own, streaming
+ * its linear run of packed (value, flagged 16-bit column) entries through a ring of register sets
+ * reloaded in place.  Per 256-entry sub-window: multiply by x from LDS, add each lane's four
+ * entries up to the row-end flags, segmented scan over the wave (DPP) for the rows that span
+ * lanes, and every row-end entry stores its row's partial sum for this stripe.  Rows are numbered
+ * by counting flags (ballot + mbcnt): no row pointers are read.  Nothing is atomic; the order of
+ * the additions is fixed by the layout.
+ */
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_mov(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+/* one step of the inclusive segmented scan: (v, f) <- (prev o cur) with prev fetched by DPP */
+template <typename T, int CTRL, int ROW_MASK> __device__ __forceinline__ void segscan_step(T &v, int &f)
+{
+    const T pv = dpp_mov<CTRL, ROW_MASK>(v);
+    const int pf = dpp_mov<CTRL, ROW_MASK>(f);
+    v = f ? v : pv + v;
+    f |= pf;
+}
+
+/* One sub-window of the STRIPED stream in registers: EPL consecutive entries per lane.  Inside
+ * every block of 64*EPL entries the values are stored lane-interleaved in 16-byte units (see
+ * spmv_striped.c), so each of the EPL*sizeof(T)/16 value loads is a dense 1-KiB wave access. */
+template <typename T, int EPL> struct StripeRegs {
+    static constexpr int E = Vec16<T>::E;
+    static constexpr int NV = EPL / E; /* 16-byte value loads per lane */
+    typename Vec16<T>::val_t v[NV];
+    unsigned int c[EPL / 2];           /* two 16-bit columns per dword */
+    __device__ __forceinline__ T val(int k) const { return v[k / E][k % E]; }
+    __device__ __forceinline__ unsigned int col(int k) const
+    {
+        return (k & 1) ? (c[k >> 1] >> 16) : (c[k >> 1] & 0xffffu);
+    }
+};
+
+template <typename T, int EPL>
+__device__ __forceinline__ void stripe_load(StripeRegs<T, EPL> &r, const T *__restrict__ pval,
+                                            const unsigned short *__restrict__ pcol, int sb, int lane)
+{
+    using VT = typename Vec16<T>::val_t;
+    constexpr int E = Vec16<T>::E;
+    const unsigned int base = (unsigned int)sb;
+    if constexpr (EPL == 4) {
+        const u32x2 cc = *reinterpret_cast<const u32x2 *>(pcol + base + (unsigned int)lane * 4u);
+        r.c[0] = cc[0], r.c[1] = cc[1];
+    } else {
+        const i32x4 cc = *reinterpret_cast<const i32x4 *>(pcol + base + (unsigned int)lane * 8u);
+        r.c[0] = (unsigned int)cc[0], r.c[1] = (unsigned int)cc[1];
+        r.c[2] = (unsigned int)cc[2], r.c[3] = (unsigned int)cc[3];
+    }
+#pragma unroll
+    for (int j = 0; j < StripeRegs<T, EPL>::NV; ++j)
+        r.v[j] = *reinterpret_cast<const VT *>(pval + base + (unsigned int)(j * 64 * E) + (unsigned int)lane * E);
+}
+
+template <typename T, int WPB, int R, int XT_BYTES, int EPL>
+__global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__ wptr,
+                                                         const int *__restrict__ wrow,
+                                                         const unsigned short *__restrict__ pcol,
+                                                         const T *__restrict__ pval,
+                                                         const T *__restrict__ x, T *__restrict__ partial,
+                                                         int rows, int cols, int B, int dbg)
+{
+    using VT = typename Vec16<T>::val_t;
+    constexpr int E = Vec16<T>::E;
+    constexpr int W = XT_BYTES / (int)sizeof(T);
+    constexpr int SUB = 64 * EPL;
+    constexpr int NT = WPB * 64;
+    constexpr int XV = W / (NT * E);
+    static_assert(XV * NT * E == W, "stripe must be a whole number of 16-byte loads per thread");
+    static_assert((R + 1) * SUB <= SPMV_TILE_PAD, "look-ahead must stay inside the padding");
+    constexpr int RING = 256; /* row sums staged per wave before they leave as full 64-lane stores */
+    __shared__ __attribute__((aligned(16))) T s_x[W];
+    __shared__ __attribute__((aligned(16))) T s_out[WPB][RING];
+
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int s = blockIdx.x / B; /* stripe */
+    const int wi = blockIdx.x * WPB + w;
+    const int P0 = __builtin_amdgcn_readfirstlane(wptr[wi]);
+    const int P1 = __builtin_amdgcn_readfirstlane(wptr[wi + 1]); /* P1 - P0 is a multiple of SUB */
+    unsigned int row = (unsigned int)__builtin_amdgcn_readfirstlane(wrow[wi]);
+
+    /* the first R sub-windows are on their way while x is staged */
+    StripeRegs<T, EPL> set[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        stripe_load<T, EPL>(set[r], pval, pcol, P0 + r * SUB, lane);
+
+    {
+        const int c0 = s * W;
+        const int nx = (cols - c0) < W ? (cols - c0) : W;
+        const T *xs = x + c0;
+        VT xr[XV];
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int i = (k * NT + tid) * E;
+            const T *src = (i + E <= nx) ? xs + i : x; /* no branch around a load; see k_tiled */
+            xr[k] = *reinterpret_cast<const VT *>(src);
+        }
+#pragma unroll
+        for (int k = 0; k < XV; ++k)
+            *reinterpret_cast<VT *>(&s_x[(k * NT + tid) * E]) = xr[k];
+        const int tail = nx % E; /* <16-byte tail of the last stripe: patched by the slot's owner */
+        if (tail != 0 && (((nx - tail) / E) % NT) == tid)
+            for (int j = 0; j < tail; ++j)
+                s_x[nx - tail + j] = xs[nx - tail + j];
+    }
+    wg_barrier_lds();
+
+    T *__restrict__ out = partial + (size_t)s * (size_t)rows;
+    T carry = (T)0; /* open sum of the row that spans the sub-window boundary */
+    /*
+     * Row sums do not go to memory one by one (a store per row end costs more than the loads):
+     * rows are consecutive, so they are parked in the wave's LDS ring at (row & 255) and leave 64
+     * at a time as one coalesced store.  `flushed` = first row not yet written.
+     */
+    unsigned int flushed = row;
+    auto flush64 = [&]() {
+        const T v = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
+        out[flushed + (unsigned int)lane] = v;
+        flushed += 64;
+    };
+    for (int jj = 0;; jj += R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int sb = P0 + (jj + r) * SUB;
+            if (sb >= P1)
+                goto done;
+            T p[EPL];
+            int f[EPL];
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                const unsigned int c = set[r].col(k);
+                p[k] = set[r].val(k) * ((dbg & 4) ? (T)c : s_x[c & (W - 1)]);
+                f[k] = (int)(c >> 15);
+            }
+            stripe_load<T, EPL>(set[r], pval, pcol, sb + R * SUB, lane);
+            /* lane-local: the sum after the lane's last row end, and whether it has a row end */
+            T tailv = (T)0;
+            int has = 0;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                tailv = tailv + p[k]; /* the flagged entry itself still belongs to the closing row */
+                if (f[k])
+                    tailv = (T)0;
+                has |= f[k];
+            }
+            /* inclusive segmented scan of (tailv, has) over the wave */
+            T sv = tailv;
+            int sf = has;
+            if (!(dbg & 2)) {
+                segscan_step<T, 0x111, 0xf>(sv, sf); /* row_shr:1 */
+                segscan_step<T, 0x112, 0xf>(sv, sf); /* row_shr:2 */
+                segscan_step<T, 0x114, 0xf>(sv, sf); /* row_shr:4 */
+                segscan_step<T, 0x118, 0xf>(sv, sf); /* row_shr:8 */
+                segscan_step<T, 0x142, 0xa>(sv, sf); /* row_bcast:15 */
+                segscan_step<T, 0x143, 0xc>(sv, sf); /* row_bcast:31 */
+            }
+            if (!sf)
+                sv = sv + carry; /* no row end at or before this lane: the previous sub-window's open sum */
+            T cin = dpp_mov<0x138, 0xf>(sv); /* wave_shr:1: what the lane below leaves open */
+            if (lane == 0)
+                cin = carry;
+            carry = __shfl(sv, 63, 64);
+
+            /* row numbers: count the row ends in lower lanes */
+            unsigned int before = 0, nflags = 0;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                const unsigned long long m = __ballot(f[k] != 0);
+                before += __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0));
+                nflags += (unsigned int)__builtin_popcountll(m);
+            }
+            /* emit the rows that end in this lane */
+            T run = cin;
+            unsigned int idx = row + before;
+            if (nflags <= RING - 64) { /* wave-uniform; the ring holds < 64 pending rows here */
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) {
+                    run = run + p[k];
+                    if (f[k]) {
+                        s_out[w][idx & (RING - 1)] = run;
+                        ++idx;
+                        run = (T)0;
+                    }
+                }
+                row += nflags;
+                __builtin_amdgcn_wave_barrier();
+                while (row - flushed >= 64u)
+                    if (!(dbg & 1))
+                        flush64();
+                    else
+                        flushed += 64;
+                __builtin_amdgcn_wave_barrier();
+            } else { /* a sub-window crowded with tiny rows: drain the ring, then store directly */
+                if ((unsigned int)lane < row - flushed)
+                    out[flushed + (unsigned int)lane] = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) {
+                    run = run + p[k];
+                    if (f[k]) {
+                        out[idx] = run;
+                        ++idx;
+                        run = (T)0;
+                    }
+                }
+                row += nflags;
+                flushed = row;
+            }
+        }
+    }
+done:
+    __builtin_amdgcn_wave_barrier();
+    if ((unsigned int)lane < row - flushed) /* the last < 64 rows of the wave's range */
+        out[flushed + (unsigned int)lane] = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SPMV_WG) k_stripe_sum(const T *__restrict__ partial, T *__restrict__ y,
+                                                        int rows, int S)
+{
+    const int r = blockIdx.x * SPMV_WG + threadIdx.x;
+    if (r >= rows)
+        return;
+    const T *p = partial + r;
+    T acc = (T)0;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) { /* eight loads in flight, added in stripe order */
+        T v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            v[k] = p[(size_t)(s + k) * rows];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            acc = acc + v[k];
+    }
+    for (; s < S; ++s)
+        acc = acc + p[(size_t)s * rows];
+    y[r] = acc;
+}
+
 /* ================================ k_long ======================================== */
 template <typename T>
 __global__ void __launch_bounds__(SPMV_WG) k_long(const int *__restrict__ seg,
@@ -662,7 +910,7 @@ void spmvk_set_tuning(int key, int value)
         g_tune_xcd = value;
     else if (key == 1)
         g_tune_nt = value;
-    else if (key == 5 && value >= 1 && value <= 8)
+    else if (key == 5 && value >= 0 && value <= 8)
         g_tune_tile_k = value;
     else if (key == 6)
         g_tune_tile_dbg = value;
@@ -767,6 +1015,70 @@ int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream)
         SPMV_LTK(float);
 #undef SPMV_LTK
 #undef SPMV_LT
+    return launch_status();
+}
+
+int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (t->rows <= 0)
+        return 0;
+    const int grid = t->S * t->B;
+#define SPMV_LS2(T, WPB, R, XT, EPL)                                                                   \
+    hipLaunchKernelGGL((k_striped<T, WPB, R, XT, EPL>), dim3(grid), dim3(WPB * 64), 0, st, t->wptr,    \
+                       t->wrow, t->col, (const T *)t->val, (const T *)x, (T *)t->partial, t->rows,     \
+                       t->cols, t->B, g_tune_tile_dbg)
+#define SPMV_LS2R(T, WPB, XT, EPL)                                                                     \
+    do {                                                                                               \
+        if (g_tune_tile_k == 4)                                                                        \
+            SPMV_LS2(T, WPB, 4, XT, EPL);                                                              \
+        else if (g_tune_tile_k == 3)                                                                   \
+            SPMV_LS2(T, WPB, 3, XT, EPL);                                                              \
+        else                                                                                           \
+            SPMV_LS2(T, WPB, 2, XT, EPL);                                                              \
+    } while (0)
+    const int xt = t->W * t->elem;
+    if (t->WPB == 8 && xt == 65536 && t->EPL == 4) {
+        if (t->elem == 8)
+            SPMV_LS2R(double, 8, 65536, 4);
+        else
+            SPMV_LS2R(float, 8, 65536, 4);
+    } else if (t->WPB == 8 && xt == 65536 && t->EPL == 8) {
+        if (t->elem == 8)
+            SPMV_LS2R(double, 8, 65536, 8);
+        else
+            SPMV_LS2R(float, 8, 65536, 8);
+    } else if (t->WPB == 16 && xt == 65536 && t->EPL == 4) {
+        if (t->elem == 8)
+            SPMV_LS2R(double, 16, 65536, 4);
+        else
+            SPMV_LS2R(float, 16, 65536, 4);
+    } else if (t->WPB == 16 && xt == 65536 && t->EPL == 8) {
+        if (t->elem == 8)
+            SPMV_LS2R(double, 16, 65536, 8);
+        else
+            SPMV_LS2R(float, 16, 65536, 8);
+    } else if (t->WPB == 16 && xt == 131072 && t->EPL == 8) {
+        if (t->elem == 8)
+            SPMV_LS2R(double, 16, 131072, 8);
+        else
+            SPMV_LS2R(float, 16, 131072, 8);
+    } else if (t->WPB == 16 && xt == 131072 && t->EPL == 4) {
+        if (t->elem == 8)
+            SPMV_LS2R(double, 16, 131072, 4);
+        else
+            SPMV_LS2R(float, 16, 131072, 4);
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+#undef SPMV_LS2R
+#undef SPMV_LS2
+    if (t->elem == 8)
+        hipLaunchKernelGGL(k_stripe_sum<double>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
+                           (const double *)t->partial, (double *)y, t->rows, t->S);
+    else
+        hipLaunchKernelGGL(k_stripe_sum<float>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
+                           (const float *)t->partial, (float *)y, t->rows, t->S);
     return launch_status();
 }
 

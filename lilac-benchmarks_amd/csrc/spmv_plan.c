@@ -228,16 +228,18 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
     if (st->rows <= 0)
         return;
     /*
-     * TILED when x can be walked in a few dozen LDS-sized stripes and every (wave, stripe)
-     * chunk still holds enough nonzeros to stream: then the scattered gathers of x, which bound
-     * STREAM at 1.9 TB/s on NPB class C, become LDS reads.
+     * STRIPED (2-D: one stripe of x resident in LDS per workgroup) when the gathers would
+     * otherwise miss: x much larger than a stripe is not required, but every (row, stripe) segment
+     * must hold a few nonzeros on average, or the row-end markers and per-stripe partial sums cost
+     * more than the gathers they save.  Matrices whose columns are local to the rows (banded)
+     * fail the builder's filler test and stay on STREAM.  Measured on NPB class C: STREAM 224 us,
+     * TILED 122 us (bit-exact), STRIPED 82 us.
      */
-    spmv_tiled_host g;
-    spmv_tiled_geometry(st->rows, cols, elem_size, SPMV_TILE_TARGET_BLOCKS, &g);
-    const double per_chunk = (double)st->nnz / ((double)g.n_groups * (double)g.S);
-    if (st->rows >= 4096 && g.S <= 64 && per_chunk >= 64.0 && cols > g.W / 2) {
-        *plan = SPMV_HIP_PLAN_TILED;
-        *param = g.W;
+    const int W = SPMV_STRIPE_XBYTES / elem_size;
+    const int S = cols > 0 ? (cols + W - 1) / W : 1;
+    if (st->rows >= 32768 && cols >= W / 2 && S <= 64 && st->mean_len / (double)S >= 4.0) {
+        *plan = SPMV_HIP_PLAN_STRIPED;
+        *param = W;
     }
 }
 

@@ -22,12 +22,21 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "spmv_golden.npz")
 EPS = {np.dtype(np.float64): 2.0 ** -53, np.dtype(np.float32): 2.0 ** -24}
 
 
+@pytest.fixture(autouse=True)
+def _release_cached_matrices(request):
+    """The default cache policy keeps the pages of cached host matrices read-only (libspmv/gpu.c
+    semantics); tests hand over temporaries, so drop the cache before numpy recycles their memory."""
+    yield
+    if "backend" in request.fixturenames:
+        request.getfixturevalue("backend").release()
+
+
 def bits(a):
     return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
 
 
 def assert_close_rows(y, y_ref, absum, lens, dtype, what=""):
-    tol = (lens.astype(np.float64) + 2.0) * EPS[np.dtype(dtype)] * absum
+    tol = (lens.astype(np.float64) + 24.0) * EPS[np.dtype(dtype)] * absum  # +24: stripe partials / scan tree
     err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
     bad = np.nonzero(~(err <= tol))[0]
     assert bad.size == 0, "%s: %d rows off, first row %d: got %r want %r tol %g" % (
@@ -52,7 +61,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
             try:
                 m.set_plan(plan, param)
             except RuntimeError as e:
-                if plan == pkg.PLAN_TILED and "not representable" in str(e):
+                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED) and "not representable" in str(e):
                     continue  # a chunk above 65535 entries: AUTO falls back to STREAM for such matrices
                 raise
             y = m.spmv_host(x)
@@ -66,7 +75,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
 
 
 def all_plans(pkg):
-    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0)]
+    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0)]
     P += [(pkg.PLAN_VECTOR, l) for l in (1, 2, 4, 8, 16, 32, 64)]
     return P
 
@@ -317,6 +326,7 @@ print("OK" if ok else "MISMATCH", s["uploads"], s["calls"], inf["plan"], inf["ro
 
 @pytest.mark.parametrize("env,uploads,exact", [
     ({"SPMV_HIP_PARTS": "3"}, 2, False),                      # 3 row partitions on one GPU + host gather
+    ({"SPMV_HIP_CACHE": "compare"}, 2, False),                # byte comparison instead of page protection
     ({"SPMV_HIP_CACHE": "off"}, 3, False),                    # gpu-slow.c semantics
     ({"SPMV_HIP_CACHE": "pointer", "SPMV_HIP_PLAN": "stream"}, 1, False),  # gpu-unsafe.c: edit goes unnoticed
     ({"SPMV_HIP_PLAN": "ordered"}, 2, True),                  # bit-exact mode through the ABI
@@ -352,7 +362,7 @@ def test_class_c_full_size(pkg, backend, oracle):
         assert inf["algorithmic_bytes"] == 436452700
         results = {}
         for plan, param in [(pkg.PLAN_AUTO, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_VECTOR, 64), (pkg.PLAN_VECTOR, 32),
-                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0), (pkg.PLAN_TILED, 0)]:
+                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0)]:
             dm.set_plan(plan, param)
             y = dm.spmv_host(x)
             results[(plan, param)] = y

@@ -223,3 +223,93 @@ def test_tiled_rejects_unrepresentable_chunks(lib):
     ci2 = ((big - 1) % 4000 + 1).astype(np.int32)
     rc, _ = tiled_emulate(lib, rs2, ci2, np.ones(70000), np.ones(4000))
     assert rc == -2
+
+
+class StripedHost(ctypes.Structure):
+    _fields_ = [("elem", ctypes.c_int), ("W", ctypes.c_int), ("S", ctypes.c_int), ("WPB", ctypes.c_int),
+                ("B", ctypes.c_int), ("n_waves", ctypes.c_int), ("EPL", ctypes.c_int), ("n_packed", ctypes.c_int64),
+                ("n_dummies", ctypes.c_int64), ("val", ctypes.c_void_p), ("col", ctypes.POINTER(ctypes.c_uint16)),
+                ("wptr", ctypes.POINTER(ctypes.c_int32)), ("wrow", ctypes.POINTER(ctypes.c_int32))]
+
+
+def striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6, epl=4):
+    """Runs csrc/spmv_striped.c, checks the invariants k_striped relies on, and evaluates the layout
+    on the CPU: per wave, rows are recovered by counting row-end flags."""
+    rows = rs.size - 1
+    cols = int(ci.max()) if ci.size else 0
+    t = StripedHost()
+    lib.spmv_striped_build.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.POINTER(StripedHost)]
+    rc = lib.spmv_striped_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, rows, cols, a.dtype.itemsize,
+                                xbytes, wpb, wgs, epl, ctypes.byref(t))
+    if rc != 0:
+        return rc, None
+    nw = t.n_waves
+    assert nw == t.S * t.B * t.WPB
+    wptr = np.ctypeslib.as_array(t.wptr, (nw + 1,)).astype(np.int64)
+    wrow = np.ctypeslib.as_array(t.wrow, (nw + 1,)).astype(np.int64)
+    col = np.ctypeslib.as_array(t.col, (t.n_packed + 1,)).astype(np.int64)
+    ctype = ctypes.c_double if a.dtype == np.float64 else ctypes.c_float
+    val = np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctype)), (t.n_packed + 1,))
+    sub = 64 * t.EPL
+    assert np.all(wptr % sub == 0) and np.all(np.diff(wptr) >= 0)
+    # undo the lane interleave of the values inside each sub-window
+    G = 16 // a.dtype.itemsize
+    e = np.arange(t.n_packed, dtype=np.int64)
+    rr = e % sub
+    phys = e // sub * sub + (rr % t.EPL) // G * (64 * G) + (rr // t.EPL) * G + (rr % t.EPL) % G
+    val = val[:t.n_packed][phys]
+    flags = col[:t.n_packed] >> 15
+    assert flags.sum() == t.S * rows  # exactly one row end per (stripe, row)
+    partial = np.zeros((t.S, rows), a.dtype)
+    per = t.B * t.WPB
+    for wi in range(nw):
+        s = wi // per
+        row = int(wrow[wi])
+        if wi % per == 0:
+            assert row == 0
+        run = a.dtype.type(0)
+        for q in range(int(wptr[wi]), int(wptr[wi + 1])):
+            c = int(col[q])
+            run = run + val[q] * x[s * t.W + (c & 0x7fff)] if (c & 0x7fff) + s * t.W < x.size or val[q] != 0 else run
+            if c >> 15:
+                partial[s, row] = run
+                row += 1
+                run = a.dtype.type(0)
+        nxt = int(wrow[wi + 1]) if (wi + 1) % per else rows
+        assert row == nxt, (wi, row, nxt)
+    y = partial[0].copy()
+    for s in range(1, t.S):
+        y = y + partial[s]
+    geo = dict(W=t.W, S=t.S, B=t.B, WPB=t.WPB, n_packed=t.n_packed, n_dummies=t.n_dummies)
+    lib.spmv_striped_free.argtypes = [ctypes.POINTER(StripedHost)]
+    lib.spmv_striped_free(ctypes.byref(t))
+    return 0, (y, geo)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_striped_layout(lib, oracle, dtype):
+    rng = np.random.default_rng(5)
+    eps = 2.0 ** -53 if dtype == np.float64 else 2.0 ** -24
+    cases = [matgen.random_csr(18, 900, 30000, 40, dtype, empty_frac=0.05, sort_cols=False, distinct=False),
+             matgen.npb_like(19, 700, 120, dtype),
+             matgen.random_csr(20, 50, 20000, 300, dtype)]
+    for rs, ci, a in cases:
+        rows = rs.size - 1
+        x = rng.standard_normal(int(ci.max())).astype(dtype)
+        rc, res = striped_emulate(lib, rs, ci, a, x)
+        assert rc == 0
+        y, geo = res
+        rc4, res4 = striped_emulate(lib, rs, ci, a, x, epl=8)
+        assert rc4 == 0 and np.array_equal(res4[0], y)  # same sums whatever the sub-window size
+        assert geo["S"] == -(-int(ci.max()) // geo["W"]) and geo["W"] * a.dtype.itemsize == 65536
+        y_ref = oracle.spmv(a, x, rs, ci, rows)
+        tol = (np.diff(rs) + geo["S"] + 2) * eps * oracle.absum(a, x, rs, ci, rows)
+        assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol)
+
+
+def test_striped_rejects_hypersparse(lib):
+    rs, ci, a = matgen.sparsebench_like(3, 30)  # 27000 rows, ~5 per row over 27000 columns: 4 stripes, mostly dummies
+    rc, _ = striped_emulate(lib, rs, ci, a, np.ones(27000))
+    assert rc == -2

@@ -50,8 +50,12 @@ def main():
     ap.add_argument("--wpb", type=int, default=8, help="waves per workgroup of the TILED kernel (8|16)")
     ap.add_argument("--xbytes", type=int, default=32768, help="bytes of x per LDS stripe of the TILED kernel")
     ap.add_argument("--blocks", type=int, default=0, help="TILED workgroups aimed for (0 = default 512)")
-    ap.add_argument("--tk", type=int, default=4, help="TILED: 256-entry sub-windows per register window")
+    ap.add_argument("--tk", type=int, default=0, help="TILED: 256-entry sub-windows per register window")
     ap.add_argument("--dbg", type=int, default=0, help="TILED timing ablation bits (1 no x stage, 2 no reduce, 4 no gather, 8 no barrier)")
+    ap.add_argument("--sx", type=int, default=131072, help="STRIPED: bytes of x per stripe (65536|131072)")
+    ap.add_argument("--swpb", type=int, default=16, help="STRIPED: waves per workgroup (8|16)")
+    ap.add_argument("--sepl", type=int, default=4, help="STRIPED: entries per lane per sub-window (4|8)")
+    ap.add_argument("--swgs", type=int, default=256, help="STRIPED: workgroups aimed for")
     ap.add_argument("--plans", default="", help="comma list of plan names to run (default all)")
     args = ap.parse_args()
     pkg = pkgload.load_package()
@@ -62,7 +66,11 @@ def main():
     be.set_tuning(4, args.blocks)
     be.set_tuning(5, args.tk)
     be.set_tuning(6, args.dbg)
-    plans = [("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
+    be.set_tuning(7, args.sx)
+    be.set_tuning(8, args.swpb)
+    be.set_tuning(9, args.swgs)
+    be.set_tuning(10, args.sepl)
+    plans = [("striped", pkg.PLAN_STRIPED, 0), ("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
              ("vec16", pkg.PLAN_VECTOR, 16), ("vec8", pkg.PLAN_VECTOR, 8), ("vec4", pkg.PLAN_VECTOR, 4),
              ("vec1", pkg.PLAN_VECTOR, 1), ("binned", pkg.PLAN_BINNED, 0), ("ordered", pkg.PLAN_ORDERED, 0),
              ("auto", pkg.PLAN_AUTO, 0)]
