@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cls", default=None, help="override the NPB class (default: C at N=1, D at N>1)")
-    ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered")
+    ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered|tiled|striped")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-npb", action="store_true", help="skip the full NPB CG run through the ABI")
     ap.add_argument("--cpu-iters", type=int, default=3, help="timed CG iterations of the CPU sample")
@@ -93,7 +93,7 @@ def main():
     if args.plan != "auto":
         name, _, par = args.plan.partition(":")
         plan = {"stream": pkg.PLAN_STREAM, "vector": pkg.PLAN_VECTOR, "binned": pkg.PLAN_BINNED,
-                "ordered": pkg.PLAN_ORDERED}[name]
+                "ordered": pkg.PLAN_ORDERED, "tiled": pkg.PLAN_TILED, "striped": pkg.PLAN_STRIPED}[name]
         dm.set_plan(plan, int(par) if par else 0)
     info = dm.info()
     x = np.random.default_rng(12345).standard_normal(m.na + 2)  # same on every rank: x is replicated
@@ -201,6 +201,14 @@ def main():
             "upload_s": round(st["t_upload"], 4), "init_s": round(st["t_init"], 4),
         }
         be.release()
+        # the same benchmark with the opt-in device-resident CG step (vectors never leave the GPU)
+        resd = m.run_cg_device(be)
+        line["npb_cg_device"] = {
+            "class": cls, "mops": round(resd["mops"], 2), "time_s": round(resd["t_bench"], 4),
+            "zeta": resd["zeta"], "err": resd["err"], "verified": bool(resd["verified"]),
+            "path": "spmv_hip_cg_* opt-in entry points: p,q,r,z,x resident in HBM, 5 kernels per CG iteration, "
+                    "host sees two norms per outer iteration",
+        }
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
         from oracle import oracle as orc  # checker / baseline only

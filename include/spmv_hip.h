@@ -102,6 +102,23 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
 int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int reps, void *stream,
                          float *ms_total);
 
+/* ---- opt-in device-resident CG step (csrc/spmv_cg.hip) ---------- */
+/*
+ * NPB's conj_grad (NPB3.3.1/CG/cg.f:447-644) with p, q, r, z, x kept on the GPU: 25 x {SpMV,
+ * p.q, z/r update + r.r, p update} without a host round trip, then r = A z and ||x - r||.
+ * Additional entry points only: spmv_harness_ is unchanged and callers that ignore these lose
+ * nothing.  FP64, square matrix, one GPU.
+ */
+typedef struct spmv_hip_cg spmv_hip_cg;
+spmv_hip_cg *spmv_hip_cg_create(spmv_hip_matrix *m);
+void spmv_hip_cg_destroy(spmv_hip_cg *c);
+int spmv_hip_cg_set_x(spmv_hip_cg *c, const double *x_host);   /* upload x[0..rows) */
+int spmv_hip_cg_fill_x(spmv_hip_cg *c, double value);          /* x = value (cg.f:216-218) */
+int spmv_hip_cg_get(spmv_hip_cg *c, int which, double *host);  /* download 0:x 1:z 2:p 3:q 4:r */
+int spmv_hip_cg_conj_grad(spmv_hip_cg *c, int cgitmax, double *rnorm);
+int spmv_hip_cg_norms(spmv_hip_cg *c, double *x_dot_z, double *z_dot_z); /* cg.f:323-327 */
+int spmv_hip_cg_x_from_z(spmv_hip_cg *c, double scale);                  /* cg.f:343-345 */
+
 /* ---- row partition for multi-GPU (pure host arithmetic, no GPU needed) ----- */
 /*
  * Splits rows into `parts` contiguous blocks of about equal nnz.

@@ -88,6 +88,17 @@ class Backend:
         L.spmv_hip_reset_stats.restype = None
         L.spmv_hip_release.restype = None
         L.spmv_hip_abi_matrix_info.argtypes = [ctypes.POINTER(Info)]
+        L.spmv_hip_cg_create.restype = ctypes.c_void_p
+        L.spmv_hip_cg_create.argtypes = [ctypes.c_void_p]
+        L.spmv_hip_cg_destroy.argtypes = [ctypes.c_void_p]
+        L.spmv_hip_cg_destroy.restype = None
+        L.spmv_hip_cg_set_x.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.spmv_hip_cg_fill_x.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        L.spmv_hip_cg_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.spmv_hip_cg_conj_grad.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.spmv_hip_cg_norms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_double)]
+        L.spmv_hip_cg_x_from_z.argtypes = [ctypes.c_void_p, ctypes.c_double]
 
     # ---- the drop-in ABI ---------------------------------------------------------------
     def harness(self, ov, a, iv, rowstr, colidx, rows):

@@ -483,6 +483,73 @@ int npb_cg_run(const npb_matrix *m, spmv_harness_fn spmv, int niter_override, in
     return 0;
 }
 
+/* cg.f:193-402 with conj_grad on the device (see npb_cg.h). */
+int npb_cg_run_device(const npb_matrix *m, const npb_cg_device_fns *f, int niter_override, int verbose,
+                      npb_result *out)
+{
+    memset(out, 0, sizeof *out);
+    const int n = m->cls.na;
+    const int niter = niter_override > 0 ? niter_override : m->cls.niter;
+    if (niter > NPB_MAX_ITER || m->row_begin != 0 || m->row_end != n)
+        return -1;
+    const double t_init0 = now_s();
+    void *dm = f->matrix_create(m->a, m->rowstr, m->colidx, n, 8, 0, 0, n, n);
+    if (!dm)
+        return -3;
+    void *cg = f->cg_create(dm);
+    if (!cg) {
+        f->matrix_destroy(dm);
+        return -3;
+    }
+    double rnorm = 0.0, zeta = 0.0, t1 = 0.0, t2 = 0.0;
+    int rc = 0;
+    /* one untimed iteration (cg.f:233-272) */
+    rc |= f->cg_fill_x(cg, 1.0);
+    rc |= f->cg_conj_grad(cg, 25, &rnorm);
+    rc |= f->cg_norms(cg, &t1, &t2);
+    rc |= f->cg_x_from_z(cg, 1.0 / sqrt(t2));
+    rc |= f->cg_fill_x(cg, 1.0); /* cg.f:281-283 */
+    out->t_init = now_s() - t_init0;
+    if (verbose)
+        printf(" Initialization time = %15.3f seconds\n", out->t_init);
+    const double t0 = now_s();
+    for (int it = 1; it <= niter && !rc; ++it) {
+        rc |= f->cg_conj_grad(cg, 25, &rnorm);
+        rc |= f->cg_norms(cg, &t1, &t2);
+        t2 = 1.0 / sqrt(t2);
+        zeta = m->cls.shift + 1.0 / t1;
+        if (verbose) {
+            if (it == 1)
+                printf("\n   iteration           ||r||                 zeta\n");
+            printf("    %5d       %20.14E%20.13f\n", it, rnorm, zeta);
+        }
+        out->zeta_hist[it - 1] = zeta;
+        out->rnorm_hist[it - 1] = rnorm;
+        rc |= f->cg_x_from_z(cg, t2);
+    }
+    out->t_bench = now_s() - t0;
+    f->cg_destroy(cg);
+    f->matrix_destroy(dm);
+    if (rc)
+        return -4;
+    out->cls = m->cls.name;
+    out->na = n;
+    out->niter = niter;
+    out->nnz = m->nnz;
+    out->spmv_calls = 26 * (int64_t)(niter + 1);
+    out->t_spmv = 0.0;
+    out->zeta = zeta;
+    out->rnorm = rnorm;
+    out->err = fabs(zeta - m->cls.zeta_verify) / m->cls.zeta_verify;
+    out->verified = (niter == m->cls.niter) && (out->err <= 1.0e-10);
+    if (out->t_bench > 0.0) {
+        const double nz = (double)m->cls.nonzer * (double)(m->cls.nonzer + 1);
+        out->mops = (double)(2.0 * niter * (double)n) * (3.0 + nz + 25.0 * (5.0 + nz) + 3.0) / out->t_bench /
+                    1000000.0;
+    }
+    return 0;
+}
+
 void npb_print_result(const npb_result *r)
 {
     printf(" Benchmark completed \n");

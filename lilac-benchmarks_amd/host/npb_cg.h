@@ -82,6 +82,26 @@ void npb_matrix_free(npb_matrix *m);
  * (verification is then skipped). */
 int npb_cg_run(const npb_matrix *m, spmv_harness_fn spmv, int niter_override, int verbose,
                npb_result *out);
+/*
+ * The same benchmark on a backend that offers the opt-in device-resident CG step
+ * (include/spmv_hip.h, spmv_hip_cg_*): the vectors stay on the GPU, the host sees only the two
+ * norms per outer iteration.  The function pointers are resolved by the caller (dlsym / ctypes) so
+ * that this driver does not link against the backend.
+ */
+typedef struct npb_cg_device_fns {
+    void *(*matrix_create)(const void *a, const int *rowstr, const int *colidx, int rows, int elem_size,
+                           int device, int row_begin, int row_end, int cols_hint);
+    void (*matrix_destroy)(void *m);
+    void *(*cg_create)(void *m);
+    void (*cg_destroy)(void *c);
+    int (*cg_fill_x)(void *c, double value);
+    int (*cg_conj_grad)(void *c, int cgitmax, double *rnorm);
+    int (*cg_norms)(void *c, double *x_dot_z, double *z_dot_z);
+    int (*cg_x_from_z)(void *c, double scale);
+} npb_cg_device_fns;
+int npb_cg_run_device(const npb_matrix *m, const npb_cg_device_fns *f, int niter_override, int verbose,
+                      npb_result *out);
+
 /* Prints the result in the layout of NPB's print_results (common/print_results.f). */
 void npb_print_result(const npb_result *r);
 

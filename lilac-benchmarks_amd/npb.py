@@ -35,6 +35,23 @@ class Result(ctypes.Structure):
         return d
 
 
+class DeviceFns(ctypes.Structure):
+    """struct npb_cg_device_fns (host/npb_cg.h): addresses of the backend's opt-in CG entry points."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("matrix_create", "matrix_destroy", "cg_create", "cg_destroy",
+                                               "cg_fill_x", "cg_conj_grad", "cg_norms", "cg_x_from_z")]
+
+    @classmethod
+    def from_backend(cls, be):
+        names = {"matrix_create": "spmv_hip_matrix_create", "matrix_destroy": "spmv_hip_matrix_destroy",
+                 "cg_create": "spmv_hip_cg_create", "cg_destroy": "spmv_hip_cg_destroy",
+                 "cg_fill_x": "spmv_hip_cg_fill_x", "cg_conj_grad": "spmv_hip_cg_conj_grad",
+                 "cg_norms": "spmv_hip_cg_norms", "cg_x_from_z": "spmv_hip_cg_x_from_z"}
+        f = cls()
+        for field, sym in names.items():
+            setattr(f, field, ctypes.cast(getattr(be.lib, sym), ctypes.c_void_p).value)
+        return f
+
+
 _lib = None
 
 
@@ -50,6 +67,8 @@ def lib():
         L.npb_cg_run.argtypes = [ctypes.POINTER(CMatrix), ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                  ctypes.POINTER(Result)]
         L.npb_class_lookup.argtypes = [ctypes.c_char, ctypes.POINTER(Class)]
+        L.npb_cg_run_device.argtypes = [ctypes.POINTER(CMatrix), ctypes.POINTER(DeviceFns), ctypes.c_int,
+                                        ctypes.c_int, ctypes.POINTER(Result)]
     return _lib
 
 
@@ -87,6 +106,16 @@ class NpbMatrix:
         rc = lib().npb_cg_run(ctypes.byref(self.c), harness_fn, niter, 1 if verbose else 0, ctypes.byref(r))
         if rc != 0:
             raise RuntimeError("npb_cg_run failed with %d" % rc)
+        return r.as_dict()
+
+    def run_cg_device(self, backend, niter=0, verbose=False):
+        """The benchmark with conj_grad on the GPU (opt-in spmv_hip_cg_* entry points)."""
+        fns = DeviceFns.from_backend(backend)
+        r = Result()
+        rc = lib().npb_cg_run_device(ctypes.byref(self.c), ctypes.byref(fns), niter, 1 if verbose else 0,
+                                     ctypes.byref(r))
+        if rc != 0:
+            raise RuntimeError("npb_cg_run_device failed with %d: %s" % (rc, backend.last_error()))
         return r.as_dict()
 
     def total_mop(self, niter=None):

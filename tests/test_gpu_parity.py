@@ -271,6 +271,21 @@ def test_npb_cg_verifies_through_the_abi(pkg, backend, oracle, cls):
     assert max(res["rnorm_hist"]) < 10 * max(ref["rnorm_hist"]) < 1e-10
 
 
+@pytest.mark.parametrize("cls", ["S", "A", "B"])
+def test_device_resident_cg_meets_npb_verification(pkg, backend, oracle, cls):
+    """Opt-in spmv_hip_cg_* entry points: conj_grad with the vectors on the GPU.
+    Its dot products are tree sums, so zeta is compared with NPB's own criterion (1e-10, cg.f:363-368)
+    and, for S/A, with the all-host run on the oracle."""
+    m = pkg.npb.NpbMatrix(cls)
+    res = m.run_cg_device(backend)
+    assert res["verified"] == 1 and res["err"] <= 1e-10, res
+    assert res["spmv_calls"] == 26 * (m.niter + 1)
+    if cls != "B":
+        ref = m.run_cg(oracle.harness_fn())
+        z0, z1 = np.array(ref["zeta_hist"]), np.array(res["zeta_hist"])
+        assert np.all(np.abs(z0 - z1) <= 1e-10 * np.abs(z0))
+
+
 # ------------------------------------------------------------------ row partition (multi-GPU path on one GPU)
 def test_row_partitions_reassemble(pkg, backend, oracle):
     rs, ci, a = matgen.npb_like(81, 5000, 200)
