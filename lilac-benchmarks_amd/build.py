@@ -24,7 +24,7 @@ def build_all(verbose=False):
     out += _make(os.path.join(PKG_DIR, "host"))
     if verbose:
         print(out)
-    for f in ("libhip-spmv.so", "libnpbcg.so", "npbcg"):
+    for f in ("libhip-spmv.so", "libnpbcg.so", "npbcg", "libspmvcallers.so", "spmvdrv"):
         if not os.path.exists(lib_path(f)):
             raise RuntimeError("build did not produce " + lib_path(f))
     return LIB_DIR

@@ -1,0 +1,87 @@
+"""Our counterparts of the SparseBench / bfs / pagerank / parboil callers (host/callers.c) and of
+their file formats, pinned on the CPU against the reference's own data files and its native.so:
+  * parboil `small`: our Matrix Market -> CSR conversion + the reference SpMV reproduce the golden
+    output file BIT FOR BIT (parboil/datasets/spmv/small/output/1138_bus.mtx.out);
+  * bfs: the bundled input.mtx converts to what SURVEY.md 8(a) a9 measured on the reference binary
+    (rows 14, nnz 239, 5 empty rows, colidx in [2,15]);
+  * SparseBench: 1 + 2*its SpMV calls, both products plain A*x, and the CRS text format round-trips.
+GPU parity of the same drivers: tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+PB = os.path.join(GOLD, "parboil_small")
+
+
+def test_parboil_small_reproduces_the_golden_output_bit_for_bit(pkg, oracle):
+    C = pkg.callers
+    m = C.pb_load(os.path.join(PB, "1138_bus.mtx"))
+    assert (m.rows, m.nnz) == (1138, 4054)
+    rs, ci, a = m.arrays()
+    assert rs[0] == 1 and np.diff(rs).min() == 2 and np.diff(rs).max() == 18
+    y = C.pb_run(m, oracle.harness_fn(np.float32), os.path.join(PB, "vector.bin"))
+    raw = np.fromfile(os.path.join(PB, "1138_bus.mtx.out"), dtype=np.uint8)
+    n = int(raw[:4].view(np.uint32)[0])
+    gold = raw[4:].view(np.float32)
+    assert n == 1138 and np.array_equal(gold.view(np.uint32), y.view(np.uint32))
+    assert C.pb_compare(gold, y) == 0  # tools/compare-output tolerances
+    C.free(m)
+
+
+def test_parboil_same_with_the_reference_build(pkg, oracle, reference):
+    C = pkg.callers
+    m = C.pb_load(os.path.join(PB, "1138_bus.mtx"))
+    y0 = C.pb_run(m, reference.harness_fn(np.float32), os.path.join(PB, "vector.bin"))
+    y1 = C.pb_run(m, oracle.harness_fn(np.float32), os.path.join(PB, "vector.bin"))
+    assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32))
+    C.free(m)
+
+
+def test_bfs_bundled_input_converts_like_the_reference(pkg, oracle):
+    C = pkg.callers
+    m = C.bfs_read(os.path.join(GOLD, "bfs", "input.mtx"))
+    rs, ci, a = m.arrays()
+    assert (m.rows, m.nnz) == (14, 239)
+    assert int((np.diff(rs) == 0).sum()) == 5 and ci.min() == 2 and ci.max() == 15
+    assert np.all(a == 1.0)
+    levels, dist = C.bfs_run(m, oracle.harness_fn(), 3)
+    assert levels >= 1 and dist[3] == 1.0 and np.all(dist == np.floor(dist))
+    C.free(m)
+
+
+def test_sparsebench_counterpart(pkg, oracle, tmp_path):
+    C = pkg.callers
+    m = C.sb_generate(10, 7)
+    rs, ci, a = m.arrays()
+    assert m.rows == 1000 and rs[0] == 1 and rs[-1] - 1 == m.nnz
+    assert ci.min() >= 1 and ci.max() <= 1000 and np.all(a >= 0)
+    lens = np.diff(rs)
+    assert lens.min() >= 1 and 4.0 < lens.mean() < 6.0
+    res = C.sb_bicg(m, oracle.harness_fn())
+    assert res["calls"] == 1 + 2 * abs(res["its"])
+    assert abs(res["hist"][0] - np.sqrt(1000.0)) < 1e-12  # r0 = A*0 - 1
+    # text format round trip (big_gen.py:52-57 / gen_crs.f:757-789)
+    path = str(tmp_path / "crsmat010u")
+    C.sb_write(path, m)
+    m2 = C.sb_read(path)
+    rs2, ci2, a2 = m2.arrays()
+    assert np.array_equal(rs, rs2) and np.array_equal(ci, ci2)
+    assert np.all(np.abs(a - a2) <= 1e-16)  # "{:20.17f}": 17 DECIMALS, i.e. the format itself rounds small values
+    head = open(path).readline()
+    assert head == "%12d%12d\n" % (1000, m.nnz)
+    C.free(m), C.free(m2)
+
+
+def test_graph_generators_and_pagerank(pkg, oracle):
+    C = pkg.callers
+    g = C.graph_grid2d(30, 20)
+    rs, ci, a = g.arrays()
+    assert g.rows == 600 and g.nnz == 2 * (29 * 20 + 30 * 19) and np.diff(rs).max() == 4
+    x, err = C.pagerank(g, oracle.harness_fn(), 50)
+    assert abs(x.sum() - 1.0) < 1e-9 and err < 1e-3 and np.all(x > 0)
+    r = C.graph_rmat(10, 8, 3)
+    rs, ci, a = r.arrays()
+    assert r.rows == 1024 and ci.min() >= 1 and ci.max() <= 1024 and np.diff(rs).max() > 50
+    C.free(g), C.free(r)

@@ -402,3 +402,55 @@ def test_class_c_full_size(pkg, backend, oracle):
     finally:
         dm.close()
         backend.release()
+
+
+# ------------------------------------------------------------------ the other callers, through the ABI
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_parboil_small_through_the_float_abi(pkg, backend, oracle):
+    """parboil/spmv cpu (50 x f_spmv_harness_, src/cpu/main.c:93-95) on the bundled `small` dataset,
+    judged with the reference's own comparator tolerances (tools/compare-output:11-36)."""
+    C = pkg.callers
+    m = C.pb_load(os.path.join(GOLD, "parboil_small", "1138_bus.mtx"))
+    vec = os.path.join(GOLD, "parboil_small", "vector.bin")
+    y = C.pb_run(m, backend.harness_fn(np.float32), vec)
+    gold = np.fromfile(os.path.join(GOLD, "parboil_small", "1138_bus.mtx.out"), dtype=np.uint8)[4:].view(np.float32)
+    assert C.pb_compare(gold, y) == 0
+    rs, ci, a = m.arrays()
+    x = np.zeros(m.cols + 2, np.float32)
+    x[: m.rows] = np.fromfile(vec, np.float32)[: m.rows]
+    assert_close_rows(y, gold, oracle.absum(a.copy(), x, rs.copy(), ci.copy(), m.rows), np.diff(rs), np.float32, "parboil small")
+    C.free(m)
+
+
+def test_bfs_driver_distances_bit_exact(pkg, backend, oracle):
+    C = pkg.callers
+    for g in (C.bfs_read(os.path.join(GOLD, "bfs", "input.mtx")), C.graph_rmat(13, 8, 5), C.graph_grid2d(64, 48)):
+        for src in (0, 5, g.rows - 1):
+            l0, d0 = C.bfs_run(g, oracle.harness_fn(), src)
+            l1, d1 = C.bfs_run(g, backend.harness_fn(), src)
+            assert l0 == l1 and np.array_equal(bits(d0), bits(d1))
+        C.free(g)
+
+
+def test_pagerank_driver(pkg, backend, oracle):
+    C = pkg.callers
+    g = C.graph_rmat(14, 8, 9)
+    x0, e0 = C.pagerank(g, oracle.harness_fn(), 30)
+    x1, e1 = C.pagerank(g, backend.harness_fn(), 30, prepare=False)  # already normalised in place
+    assert np.all(np.abs(x0 - x1) <= 1e-12 * np.abs(x0).max()) and abs(e0 - e1) <= 1e-10
+    C.free(g)
+
+
+def test_sparsebench_bicg_driver(pkg, backend, oracle):
+    """The reference's pseudo-BiCG diverges on big_gen matrices, so only the first
+    iterations are comparable; the call count is structural."""
+    C = pkg.callers
+    m = C.sb_generate(24, 170)
+    r0 = C.sb_bicg(m, oracle.harness_fn())
+    r1 = C.sb_bicg(m, backend.harness_fn())
+    assert r1["calls"] == r0["calls"] == 1 + 2 * abs(r0["its"]) and r0["its"] == r1["its"]
+    k = 4
+    assert np.all(np.abs(r0["hist"][:k] - r1["hist"][:k]) <= 1e-6 * np.abs(r0["hist"][:k]))
+    C.free(m)
