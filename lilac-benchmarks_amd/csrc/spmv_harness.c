@@ -47,12 +47,17 @@
  *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
  *                      than devices wraps around -- lets the multi-GPU code path
  *                      run on one GPU
- *   SPMV_HIP_PIN     = staging (default) | register | pageable
+ *   SPMV_HIP_PIN     = auto (default) | staging | register | pageable
+ *                      auto: vectors with static storage duration (Fortran COMMON, C globals --
+ *                      recognised with dladdr) are pinned in place once, everything else goes
+ *                      through pinned staging buffers; register: pin whatever the caller passes
+ *                      (only safe if the caller never frees it); pageable: plain hipMemcpy
  *   SPMV_HIP_STATS   = 1: summary on stderr at exit; 2: also synchronise
  *                      between the phases of every call to attribute time
  *   SPMV_HIP_VERBOSE = 1: log uploads / invalidations
  */
 #define _GNU_SOURCE
+#include <dlfcn.h>
 #include <errno.h>
 #include <pthread.h>
 #include <signal.h>
@@ -72,7 +77,7 @@
 
 enum { CACHE_MPROTECT = 0, CACHE_POINTER = 1, CACHE_OFF = 2, CACHE_COMPARE = 3 };
 #define MIN_PROTECT_PAGES 64 /* arrays with fewer whole pages are compared byte for byte instead */
-enum { PIN_STAGING = 0, PIN_REGISTER = 1, PIN_PAGEABLE = 2 };
+enum { PIN_STAGING = 0, PIN_REGISTER = 1, PIN_PAGEABLE = 2, PIN_AUTO = 3 };
 
 /* one guarded host array: [p, p+bytes) */
 typedef struct guard {
@@ -374,14 +379,16 @@ static void lazy_init(void)
         else if (strcmp(v, "mprotect"))
             die("SPMV_HIP_CACHE=%s: expected mprotect|compare|pointer|off", v);
     }
-    G.pin = PIN_STAGING;
+    G.pin = PIN_AUTO;
     if ((v = getenv("SPMV_HIP_PIN"))) {
         if (!strcmp(v, "register"))
             G.pin = PIN_REGISTER;
         else if (!strcmp(v, "pageable"))
             G.pin = PIN_PAGEABLE;
-        else if (strcmp(v, "staging"))
-            die("SPMV_HIP_PIN=%s: expected staging|register|pageable", v);
+        else if (!strcmp(v, "staging"))
+            G.pin = PIN_STAGING;
+        else if (strcmp(v, "auto"))
+            die("SPMV_HIP_PIN=%s: expected auto|staging|register|pageable", v);
     }
     G.plan = SPMV_HIP_PLAN_AUTO;
     G.plan_param = 0;
@@ -574,6 +581,31 @@ static int ensure_registered(const void *p, size_t bytes)
     return 1;
 }
 
+/*
+ * SPMV_HIP_PIN=auto: a vector with static storage duration (a Fortran COMMON block such as
+ * NPB's p/q/r/z, NPB3.3.1/CG/cg.f:69-80, or a C global) lives inside a loaded ELF object, which
+ * dladdr() can tell; such memory is never freed and re-mapped, so pinning it in place is safe and
+ * saves the two staging copies per call.  Heap and stack vectors keep going through staging.
+ */
+static int has_static_storage(const void *p, size_t bytes)
+{
+    Dl_info a, b;
+    if (bytes == 0 || !dladdr(p, &a) || !a.dli_fbase)
+        return 0;
+    if (!dladdr((const char *)p + bytes - 1, &b) || b.dli_fbase != a.dli_fbase)
+        return 0;
+    return 1;
+}
+
+static int use_in_place(const void *p, size_t bytes)
+{
+    if (G.pin == PIN_PAGEABLE)
+        return 1;
+    if (G.pin == PIN_REGISTER || (G.pin == PIN_AUTO && has_static_storage(p, bytes)))
+        return ensure_registered(p, bytes);
+    return 0;
+}
+
 /* ---------------------------------------------------------------- the call */
 
 static void *harness(void *ov, const void *a, const void *iv, const int *rowstr, const int *colidx,
@@ -624,7 +656,7 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
 
     /* x: host -> every part's device (libspmv/gpu.c:264) */
     const void *xsrc = iv;
-    if (G.pin == PIN_STAGING || (G.pin == PIN_REGISTER && !ensure_registered(iv, xbytes))) {
+    if (!use_in_place(iv, xbytes)) {
         void *xs = stage_buf(&G.xstage, &G.xstage_n, xbytes);
         memcpy(xs, iv, xbytes);
         xsrc = xs;
@@ -653,7 +685,7 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
     /* y: each part's slice straight to its place in ov -- the host gather (libspmv/gpu.c:285) */
     char *ydst = (char *)ov;
     int y_staged = 0;
-    if (G.pin == PIN_STAGING || (G.pin == PIN_REGISTER && !ensure_registered(ov, ybytes))) {
+    if (!use_in_place(ov, ybytes)) {
         ydst = (char *)stage_buf(&G.ystage, &G.ystage_n, ybytes);
         y_staged = 1;
     }

@@ -394,21 +394,24 @@ static void conj_grad(cg_ctx *c, double *x, double *z, double *p, double *q, dou
     *rnorm = sqrt(sum);
 }
 
+/* The CG vectors have static storage duration like the Fortran COMMON block /main_flt_mem/
+ * (cg.f:69-80), dimensioned for the largest class behind the ABI (D: na = 1500000). */
+#define NPB_NA_MAX 1500000
+static double g_x[NPB_NA_MAX + 2], g_z[NPB_NA_MAX + 2], g_p[NPB_NA_MAX + 2], g_q[NPB_NA_MAX + 2],
+    g_r[NPB_NA_MAX + 2];
+
 int npb_cg_run(const npb_matrix *m, spmv_harness_fn spmv, int niter_override, int verbose,
                npb_result *out)
 {
     memset(out, 0, sizeof *out);
     const int n = m->cls.na;
     const int niter = niter_override > 0 ? niter_override : m->cls.niter;
-    if (niter > NPB_MAX_ITER || m->row_begin != 0 || m->row_end != n)
+    if (niter > NPB_MAX_ITER || m->row_begin != 0 || m->row_end != n || n > NPB_NA_MAX)
         return -1; /* the benchmark loop needs the whole matrix */
-    double *x = calloc((size_t)n + 2, sizeof *x), *z = calloc((size_t)n + 2, sizeof *z);
-    double *p = calloc((size_t)n + 2, sizeof *p), *q = calloc((size_t)n + 2, sizeof *q);
-    double *r = calloc((size_t)n + 2, sizeof *r);
-    if (!x || !z || !p || !q || !r) {
-        free(x), free(z), free(p), free(q), free(r);
-        return -2;
-    }
+    double *x = g_x, *z = g_z, *p = g_p, *q = g_q, *r = g_r;
+    memset(x, 0, ((size_t)n + 2) * sizeof *x), memset(z, 0, ((size_t)n + 2) * sizeof *z);
+    memset(p, 0, ((size_t)n + 2) * sizeof *p), memset(q, 0, ((size_t)n + 2) * sizeof *q);
+    memset(r, 0, ((size_t)n + 2) * sizeof *r);
     cg_ctx c = {m, spmv, 0.0, 0};
     double rnorm = 0.0, zeta = 0.0;
 
@@ -479,7 +482,6 @@ int npb_cg_run(const npb_matrix *m, spmv_harness_fn spmv, int niter_override, in
         out->mops = (double)(2.0 * niter * (double)n) * (3.0 + nz + 25.0 * (5.0 + nz) + 3.0) /
                     out->t_bench / 1000000.0;
     }
-    free(x), free(z), free(p), free(q), free(r);
     return 0;
 }
 
