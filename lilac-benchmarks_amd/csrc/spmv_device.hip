@@ -518,6 +518,7 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     m->ds.WPB = th.WPB;
     m->ds.B = th.B;
     m->ds.EPL = th.EPL;
+    m->ds.xbytes = g_stripe_xbytes;
     m->ds.rows = m->rows;
     m->ds.cols = m->cols;
     m->device_bytes += (nw + 1) * 8 + n_alloc * (2 + (size_t)m->elem) + pbytes;

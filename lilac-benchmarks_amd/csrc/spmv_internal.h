@@ -178,6 +178,7 @@ typedef struct spmv_dev_striped {
     const void *val;
     void *partial; /* T[S * rows] */
     int elem, W, S, WPB, B, EPL, rows, cols;
+    int xbytes; /* LDS stripe capacity (65536 / 131072) the layout was built for */
 } spmv_dev_striped;
 int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream);
 /* analysis: max(colidx[0..nnz)) -> *d_out (int, device), must be zeroed first */

@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__
                                                          const unsigned short *__restrict__ pcol,
                                                          const T *__restrict__ pval,
                                                          const T *__restrict__ x, T *__restrict__ partial,
-                                                         int rows, int cols, int B, int dbg)
+                                                         int rows, int cols, int B, int wcols, int dbg)
 {
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E;
@@ -617,8 +617,8 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__
         stripe_load<T, EPL>(set[r], pval, pcol, P0 + r * SUB, lane);
 
     {
-        const int c0 = s * W;
-        const int nx = (cols - c0) < W ? (cols - c0) : W;
+        const int c0 = s * wcols; /* wcols <= W columns per stripe (spmv_striped_geometry) */
+        const int nx = (cols - c0) < wcols ? (cols - c0) : wcols;
         const T *xs = x + c0;
         VT xr[XV];
 #pragma unroll
@@ -1027,7 +1027,7 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
 #define SPMV_LS2(T, WPB, R, XT, EPL)                                                                   \
     hipLaunchKernelGGL((k_striped<T, WPB, R, XT, EPL>), dim3(grid), dim3(WPB * 64), 0, st, t->wptr,    \
                        t->wrow, t->col, (const T *)t->val, (const T *)x, (T *)t->partial, t->rows,     \
-                       t->cols, t->B, g_tune_tile_dbg)
+                       t->cols, t->B, t->W, g_tune_tile_dbg)
 #define SPMV_LS2R(T, WPB, XT, EPL)                                                                     \
     do {                                                                                               \
         if (g_tune_tile_k == 4)                                                                        \
@@ -1037,7 +1037,7 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
         else                                                                                           \
             SPMV_LS2(T, WPB, 2, XT, EPL);                                                              \
     } while (0)
-    const int xt = t->W * t->elem;
+    const int xt = t->xbytes; /* LDS stripe capacity the layout was built for; t->W <= xt / elem */
     if (t->WPB == 8 && xt == 65536 && t->EPL == 4) {
         if (t->elem == 8)
             SPMV_LS2R(double, 8, 65536, 4);

@@ -237,7 +237,7 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
      */
     const int W = SPMV_STRIPE_XBYTES / elem_size;
     const int S = cols > 0 ? (cols + W - 1) / W : 1;
-    if (st->rows >= 32768 && cols >= W / 2 && S <= 64 && st->mean_len / (double)S >= 4.0) {
+    if (st->rows >= 32768 && cols >= W / 2 && S <= 128 && st->mean_len / (double)S >= 4.0) {
         *plan = SPMV_HIP_PLAN_STRIPED;
         *param = W;
     }

@@ -52,18 +52,29 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, int xbytes, int wp
     memset(t, 0, sizeof *t);
     t->elem = elem_size;
     t->EPL = epl == 4 ? 4 : 8;
-    t->W = xbytes / elem_size;
-    if (t->W > 32768)
-        t->W = 32768; /* 15 column bits */
-    t->S = cols > 0 ? (cols + t->W - 1) / t->W : 1;
     t->WPB = wpb;
-    int b = target_wgs / t->S; /* S*B <= target: every workgroup is resident at once, no tail round */
-    if (b < 1)
-        b = 1;
+    int wmax = xbytes / elem_size; /* columns that fit the LDS stripe buffer */
+    if (wmax > 32768)
+        wmax = 32768; /* 15 column bits */
+    if (target_wgs < 1)
+        target_wgs = 1;
+    /*
+     * Widest stripes that fit LDS (fewest partial sums per row), then as many row ranges per
+     * stripe as keep S * B within the target: every workgroup is resident at once, no tail round.
+     * Narrower stripes that fill the last workgroup slots were measured and lose: on a class D row
+     * block S = 125 (250 workgroups) ran 270 us against 250 us for S = 92 (184 workgroups), because
+     * every extra stripe adds a row-end marker and a partial sum per row.
+     */
+    const int s_min = cols > 0 ? (cols + wmax - 1) / wmax : 1;
+    int best_w = wmax, best_s = s_min, best_b = target_wgs / s_min > 0 ? target_wgs / s_min : 1;
+    if (best_b < 1)
+        best_b = 1;
     /* no point in more waves than rows */
-    while (b > 1 && (int64_t)b * wpb > (int64_t)rows)
-        --b;
-    t->B = b;
+    while (best_b > 1 && (int64_t)best_b * wpb > (int64_t)rows)
+        --best_b;
+    t->W = best_w;
+    t->S = best_s;
+    t->B = best_b;
 }
 
 /*

@@ -303,7 +303,8 @@ def test_striped_layout(lib, oracle, dtype):
         y, geo = res
         rc4, res4 = striped_emulate(lib, rs, ci, a, x, epl=8)
         assert rc4 == 0 and np.array_equal(res4[0], y)  # same sums whatever the sub-window size
-        assert geo["S"] == -(-int(ci.max()) // geo["W"]) and geo["W"] * a.dtype.itemsize == 65536
+        assert geo["S"] == -(-int(ci.max()) // geo["W"]) and geo["W"] * a.dtype.itemsize <= 65536
+        assert geo["S"] * geo["B"] <= 6 and geo["W"] % 128 == 0
         y_ref = oracle.spmv(a, x, rs, ci, rows)
         tol = (np.diff(rs) + geo["S"] + 2) * eps * oracle.absum(a, x, rs, ci, rows)
         assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol)

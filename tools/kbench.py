@@ -24,6 +24,10 @@ def build_case(pkg, name, dtype):
         m = pkg.npb.NpbMatrix(name)
         a = m.a if dtype == np.float64 else m.a.astype(np.float32)
         return m.rowstr, m.colidx, a, m  # keep m alive
+    if name.startswith("D/"):  # one block of the class D row partition, e.g. D/8 = part 3 of 8 (x has 1.5 M entries)
+        parts = int(name[2:])
+        m = pkg.npb.NpbMatrix("D", part=min(3, parts - 1), nparts=parts)
+        return m.rowstr, m.colidx, m.a.astype(dtype), m
     if name == "cband":  # class C row lengths and values, but columns consecutive from the diagonal: local gathers
         m = pkg.npb.NpbMatrix("C")
         lens = np.diff(m.rowstr)
@@ -81,7 +85,7 @@ def main():
             t0 = time.time()
             rs, ci, a, keep = build_case(pkg, case, dtype)
             rows = rs.size - 1
-            dm = be.matrix(a, rs, ci, rows)
+            dm = be.matrix(a, rs, ci, rows, cols_hint=(keep.na if case.startswith("D/") else 0))
             inf = dm.info()
             x = np.random.default_rng(1).standard_normal(inf["cols"] + 2).astype(dtype)
             dx = be.malloc(x.nbytes)
