@@ -65,10 +65,17 @@ def main():
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     n_gpus = world
     dist = None
+    # rehearsal aid: BENCH_DIST_BACKEND=gloo lets several ranks share the one GPU of a test box
+    # (RCCL refuses two ranks on one device); the driver's real runs use nccl = RCCL, one GPU per rank
+    backend_name = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % max(ndev, 1))
+        if backend_name == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend_name)
 
     pkg = pkgload.load_package()
     if not os.path.exists(pkg.lib_path()):
@@ -76,8 +83,9 @@ def main():
     be = pkg.Backend()
     if be.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libhip-spmv.so has no CPU fallback")
-    device = local_rank if world > 1 else 0
+    device = (local_rank % max(ndev, 1)) if world > 1 else 0
     torch.cuda.set_device(device)
+    red_dev = "cuda" if backend_name == "nccl" else "cpu"
 
     cls = args.cls or ("C" if n_gpus == 1 else "D")
     t0 = time.time()
@@ -119,10 +127,10 @@ def main():
 
     nnz_total = float(m.nnz)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([float(m.nnz)], dtype=torch.float64, device="cuda")
+        s = torch.tensor([float(m.nnz)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         nnz_total = float(s.item())
 
