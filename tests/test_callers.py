@@ -85,3 +85,15 @@ def test_graph_generators_and_pagerank(pkg, oracle):
     rs, ci, a = r.arrays()
     assert r.rows == 1024 and ci.min() >= 1 and ci.max() <= 1024 and np.diff(rs).max() > 50
     C.free(g), C.free(r)
+
+
+def test_cli_drivers_with_the_oracle_backend(pkg, oracle):
+    """npbcg / spmvdrv load any backend by path; here the oracle .so (CPU), same CSV shape as the reference."""
+    import subprocess
+    out = subprocess.run([pkg.lib_path("npbcg"), "S", oracle.path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=120)
+    assert out.returncode == 0 and "VERIFICATION SUCCESSFUL" in out.stdout
+    assert out.stdout.strip().splitlines()[-1].startswith("mi355x,NPB,oracle,S,")
+    out = subprocess.run([pkg.lib_path("spmvdrv"), "sb", oracle.path, "8", "3"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0 and "spmv_calls=201" in out.stdout and ",SparseBench,oracle,8," in out.stdout

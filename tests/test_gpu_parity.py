@@ -454,3 +454,41 @@ def test_sparsebench_bicg_driver(pkg, backend, oracle):
     k = 4
     assert np.all(np.abs(r0["hist"][:k] - r1["hist"][:k]) <= 1e-6 * np.abs(r0["hist"][:k]))
     C.free(m)
+
+
+def test_pathsample_shaped_calls(backend, oracle):
+    """wales/PATHSAMPLE/source/Pfold.f90:219-223: NPFOLD calls with rows passed as the temporary
+    NMIN-1 (fewer rows than the row pointer array describes), more columns than rows, and one of the
+    value arrays rewritten by the caller between calls -- every call must see the new contents."""
+    rs, ci, a = matgen.random_csr(131, 6001, 9000, 14)
+    nmin = 6001
+    rng = np.random.default_rng(131)
+    x = rng.standard_normal(9000)
+    y = np.empty(nmin)
+    backend.reset_stats()
+    for it in range(4):
+        a[:] = rng.standard_normal(a.size)  # the caller rewrites the array it passes as `a`
+        backend.harness(y, a, x, rs, ci, nmin - 1)
+        ref = oracle.spmv(a, x, rs, ci, nmin - 1)
+        assert_close_rows(y[: nmin - 1], ref, oracle.absum(a, x, rs, ci, nmin - 1), np.diff(rs)[: nmin - 1],
+                          np.float64, "pfold call %d" % it)
+    s = backend.stats()
+    assert s["calls"] == 4 and s["uploads"] == 4  # each rewrite was noticed
+
+
+def test_cli_drivers_on_the_hip_backend(pkg):
+    """The command-line counterparts (npbcg, spmvdrv) dlopen the backend like pagerank/main.cpp does."""
+    lib = pkg.lib_path()
+    out = subprocess.run([pkg.lib_path("npbcg"), "S", lib, "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and "VERIFICATION SUCCESSFUL" in out.stdout, out.stdout + out.stderr
+    row = out.stdout.strip().splitlines()[-1].split(",")
+    assert row[:4] == ["mi355x", "NPB", "hip", "S"] and len(row) == 6  # reference CSV shape, run_all:36-41
+    gold = os.path.join(GOLD, "parboil_small")
+    out = subprocess.run([pkg.lib_path("spmvdrv"), "parboil", lib, os.path.join(gold, "1138_bus.mtx"),
+                          os.path.join(gold, "vector.bin"), "-", os.path.join(gold, "1138_bus.mtx.out")],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0 and "compare-output: Pass" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([pkg.lib_path("spmvdrv"), "bfs", lib, os.path.join(GOLD, "bfs", "input.mtx"), "4"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0 and "rows=14 nnz=239" in out.stdout, out.stdout + out.stderr
