@@ -585,7 +585,7 @@ static int ensure_registered(const void *p, size_t bytes)
  * SPMV_HIP_PIN=auto: a vector with static storage duration (a Fortran COMMON block such as
  * NPB's p/q/r/z, NPB3.3.1/CG/cg.f:69-80, or a C global) lives inside a loaded ELF object, which
  * dladdr() can tell; such memory is never freed and re-mapped, so pinning it in place is safe and
- * saves the two staging copies per call.  Heap and stack vectors keep going through staging.
+ * saves the two staging copies per call.  Heap and stack vectors are never pinned by us.
  */
 static int has_static_storage(const void *p, size_t bytes)
 {
@@ -597,12 +597,23 @@ static int has_static_storage(const void *p, size_t bytes)
     return 1;
 }
 
+/*
+ * Which way a host vector crosses PCIe (measured on MI355X, profiles/r01_abi_transfer_modes.log):
+ * pinned in place is the fastest and is what static vectors get; a heap or stack vector of a
+ * megabyte or more is handed to the runtime as it is (its pageable path pins the pages for the
+ * duration of the copy and moves 39 MB in 0.9 ms, where memcpy into our staging buffer plus the DMA
+ * takes 2.3 ms); below that the fixed cost of the pageable path loses to the staging buffer.
+ */
+#define DIRECT_PAGEABLE_MIN_BYTES ((size_t)1 << 20)
+
 static int use_in_place(const void *p, size_t bytes)
 {
     if (G.pin == PIN_PAGEABLE)
         return 1;
     if (G.pin == PIN_REGISTER || (G.pin == PIN_AUTO && has_static_storage(p, bytes)))
         return ensure_registered(p, bytes);
+    if (G.pin == PIN_AUTO && bytes >= DIRECT_PAGEABLE_MIN_BYTES)
+        return 1;
     return 0;
 }
 
