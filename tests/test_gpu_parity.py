@@ -492,3 +492,41 @@ def test_cli_drivers_on_the_hip_backend(pkg):
     out = subprocess.run([pkg.lib_path("spmvdrv"), "bfs", lib, os.path.join(GOLD, "bfs", "input.mtx"), "4"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert out.returncode == 0 and "rows=14 nnz=239" in out.stdout, out.stdout + out.stderr
+
+
+def test_sparsebench_170_full_size(pkg, backend, oracle):
+    """BASELINE configs[2] at its full size: crsmat170u has 170^3 = 4 913 000 rows (big_gen.py:60-83,
+    seeded stand-in); one product against the oracle row by row, then linearity A(x+2z) = Ax + 2Az,
+    which does not need the oracle."""
+    C = pkg.callers
+    m = C.sb_generate(170, 170)
+    rs, ci, a = m.arrays()
+    rng = np.random.default_rng(170)
+    x = rng.standard_normal(m.cols)
+    z = rng.standard_normal(m.cols)
+    y = np.empty(m.rows)
+    backend.harness(y, a, x, rs, ci, m.rows)
+    assert_close_rows(y, oracle.spmv(a, x, rs, ci, m.rows), oracle.absum(a, x, rs, ci, m.rows), np.diff(rs),
+                      np.float64, "sb170")
+    yz, yc = np.empty(m.rows), np.empty(m.rows)
+    backend.harness(yz, a, z, rs, ci, m.rows)
+    backend.harness(yc, a, x + 2.0 * z, rs, ci, m.rows)
+    lens = np.diff(rs)
+    tol = (lens + 24) * 4 * np.finfo(np.float64).eps * (oracle.absum(a, np.abs(x) + 2 * np.abs(z), rs, ci, m.rows))
+    assert np.all(np.abs(yc - (y + 2.0 * yz)) <= tol)
+    assert backend.stats()["uploads"] >= 1
+    C.free(m)
+
+
+def test_graph_callers_at_scale(pkg, backend, oracle):
+    """BASELINE configs[3]: bfs and pagerank on a 2^20-vertex R-MAT graph (16 M edges, rows from 0 to
+    ~40 000 nonzeros): BFS distances bit-exact against the oracle, PageRank within 1e-12 of it."""
+    C = pkg.callers
+    g = C.graph_rmat(20, 16, 20)
+    l0, d0 = C.bfs_run(g, oracle.harness_fn(), 1)
+    l1, d1 = C.bfs_run(g, backend.harness_fn(), 1)
+    assert l0 == l1 and l1 > 2 and np.array_equal(bits(d0), bits(d1))
+    x0, e0 = C.pagerank(g, oracle.harness_fn(), 10)
+    x1, e1 = C.pagerank(g, backend.harness_fn(), 10, prepare=False)
+    assert np.all(np.abs(x0 - x1) <= 1e-12 * np.abs(x0).max()) and abs(e0 - e1) <= 1e-10
+    C.free(g)
