@@ -107,6 +107,7 @@ struct spmv_hip_matrix {
     size_t tiled_bytes = 0;
     /* STRIPED (built on demand) */
     bool have_striped = false;
+    bool striped_mostly_filler = false;
     int striped_rc = 0;
     spmv_dev_striped ds{};
 };
@@ -434,8 +435,15 @@ static int g_stripe_xbytes = SPMV_STRIPE_XBYTES, g_stripe_wpb = SPMV_STRIPE_WPB,
 static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *host_col, int64_t first,
                           bool auto_choice)
 {
-    if (m->have_striped)
+    if (m->have_striped) {
+        /* built earlier on explicit request: the automatic choice still declines a layout that is
+         * mostly filler */
+        if (auto_choice && m->striped_mostly_filler) {
+            m->striped_rc = -2;
+            return -2;
+        }
         return 0;
+    }
     void *tmp_a = nullptr;
     int *tmp_c = nullptr;
     if (!host_a) {
@@ -465,9 +473,10 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
                                                host_col + shift, 0, m->rows, m->cols, m->elem, g_stripe_xbytes,
                                                g_stripe_wpb, g_stripe_wgs, g_stripe_epl, &th);
     free(tmp_a), free(tmp_c);
-    if (rc == 0 && auto_choice && th.n_dummies * 2 > (int64_t)th.S * m->rows) {
-        /* most (row, stripe) pairs are empty: the columns are local to the rows, x gathers already
-         * hit in cache and the STREAM kernel is the better plan (measured: 73 us vs 133 us) */
+    /* most (row, stripe) pairs are empty: the columns are local to the rows, x gathers already
+     * hit in cache and the STREAM kernel is the better plan (measured: 73 us vs 133 us) */
+    m->striped_mostly_filler = rc == 0 && th.n_dummies * 2 > (int64_t)th.S * m->rows;
+    if (auto_choice && m->striped_mostly_filler) {
         spmv_striped_free(&th);
         rc = -2;
     }

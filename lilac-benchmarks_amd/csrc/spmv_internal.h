@@ -20,7 +20,7 @@ extern "C" {
 #define SPMV_STREAM_NPT 8         /* nonzeros per thread per row block in the STREAM kernel  */
 #define SPMV_STREAM_CAP (SPMV_WG * SPMV_STREAM_NPT) /* = 2048 nonzeros per row block         */
 #define SPMV_STREAM_ROWCAP 512    /* rows per row block (row pointers staged in LDS)          */
-#define SPMV_LONG_SEG 16384       /* nonzeros per workgroup in the long-row kernel            */
+#define SPMV_LONG_SEG 2048        /* nonzeros per workgroup in the long-row kernel            */
 #define SPMV_PAD_ELEMS 4096       /* a/colidx are over-allocated by this many entries         */
                                   /* (a = 0, colidx = 1) so aligned vector loads may overrun  */
 #define SPMV_NBINS 4              /* BINNED plan: lanes per row 1 / 4 / 16 / 64               */

@@ -10,7 +10,8 @@
  * are read exactly once with 16-byte-per-lane coalesced loads, that x[] stays
  * in L2, and that enough bytes are in flight per CU.
  *
- * Kernel family (all 256-thread workgroups = 4 wavefronts of 64):
+ * Kernel family (256-thread workgroups = 4 wavefronts of 64, except k_tiled: 8 waves and
+ * k_striped: 16 waves):
  *
  *   k_ordered   one lane per row, sequential, multiply then add with FP
  *               contraction off: bit-identical to the reference loop.
@@ -22,9 +23,16 @@
  *               rows start, multiplies by the gathered x, parks the products in
  *               LDS, then lane groups (1..64 lanes, chosen per block) reduce each
  *               row out of LDS.
- *   k_long      rows longer than a row block: one workgroup per 16384-nonzero
+ *   k_long      rows longer than a row block: one workgroup per 2048-nonzero
  *               segment, partial sums combined in fixed order by k_long_finish
  *               (no float atomics: results are reproducible run to run).
+ *   k_tiled     row blocks x column stripes with the stripe of x double-buffered in
+ *               LDS; one lane per row adds in stored order (bit-exact on sorted
+ *               columns).  Layout: spmv_tiled.c.
+ *   k_striped   2-D decomposition, a workgroup keeps ONE stripe of x in LDS for its
+ *               whole life and streams packed (value, 16-bit column) entries;
+ *               k_stripe_sum adds the per-stripe partial sums.  Layout:
+ *               spmv_striped.c.  The NPB class B/C/D kernel.
  *
  * Column ids stay 1-based as the ABI delivers them; kernels index x through
  * (x - 1).  a/colidx are over-allocated by SPMV_PAD_ELEMS entries (a = 0,
@@ -283,6 +291,13 @@ __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
     while (G > 1 && (G * nrows > SPMV_WG || G > 2 * ((n + nrows - 1) / (nrows > 0 ? nrows : 1))))
         G >>= 1;
 
+    /* A row much longer than its block's average would keep one small lane group busy long after
+     * the others are done (R-MAT blocks: 130 rows of ~15 entries and one of 2000).  Lane groups
+     * leave such rows alone; afterwards every wave gives all 64 lanes to each of the ones it finds
+     * among its share of the rows. */
+    const int far = G >= 64 ? CAP : (32 * G > 64 ? 32 * G : 64);
+    int skipped = 0;
+
 #define SPMV_REDUCE_ROWS(GG)                                                         \
     {                                                                                \
         constexpr int NG = SPMV_WG / GG;                                             \
@@ -291,6 +306,10 @@ __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
          * combines lanes that are active together */                              \
         for (int rr = grp; rr < nrows; rr += NG) {                                   \
             const int ps = s_rp[rr], pe = s_rp[rr + 1];                              \
+            if (pe - ps > far) {                                                     \
+                skipped = 1;                                                         \
+                continue;                                                            \
+            }                                                                        \
             T acc = (T)0;                                                            \
             for (int k = ps + gl; k < pe; k += GG)                                   \
                 acc += s_prod[k];                                                    \
@@ -307,6 +326,28 @@ __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
     case 4: SPMV_REDUCE_ROWS(4) break;
     case 2: SPMV_REDUCE_ROWS(2) break;
     default: SPMV_REDUCE_ROWS(1) break;
+    }
+    if (!__syncthreads_or(skipped)) /* the usual case: nothing was left behind */
+        return;
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int base_r = 0; base_r < nrows; base_r += SPMV_WG) {
+            const int rr = base_r + wave * 64 + lane;
+            const bool mine = rr < nrows && (s_rp[rr < nrows ? rr + 1 : 0] - s_rp[rr < nrows ? rr : 0]) > far;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(mine);
+            while (todo) {
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int row = base_r + wave * 64 + l;
+                const int ps = s_rp[row], pe = s_rp[row + 1];
+                T acc = (T)0;
+                for (int k = ps + lane; k < pe; k += 64)
+                    acc += s_prod[k];
+                acc = group_sum<T, 64>(acc);
+                if (lane == 63)
+                    y[r0 + row] = acc;
+            }
+        }
     }
 #undef SPMV_REDUCE_ROWS
 }
@@ -786,15 +827,35 @@ __global__ void __launch_bounds__(SPMV_WG) k_long(const int *__restrict__ seg,
     const i32x4 d = *reinterpret_cast<const i32x4 *>(seg + 4 * blockIdx.x);
     const int row = d[0], sb = d[1], se = d[2], slot = d[3];
     const int tid = threadIdx.x;
+    /* A segment is a handful of 16-byte loads per thread: all of them (and then all the gathers)
+     * are issued before the first product, so a workgroup pays the memory latency about twice,
+     * not once per pass.  Slots beyond the segment re-read its first vector and contribute 0. */
+    constexpr int U = SPMV_LONG_SEG / (SPMV_WG * E) + 1; /* +1: sb need not be 16-byte aligned */
+    const int j0 = (sb & ~(E - 1)) + tid * E;
+    IT c[U];
+    VT v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = j0 + u * SPMV_WG * E;
+        const int jl = j < se ? j : j0;
+        c[u] = *reinterpret_cast<const IT *>(colidx + jl);
+        v[u] = *reinterpret_cast<const VT *>(val + jl);
+    }
+    T xv[U][E];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            xv[u][i] = xm1[c[u][i]];
     T acc = (T)0;
-    for (int j = (sb & ~(E - 1)) + tid * E; j < se; j += SPMV_WG * E) {
-        IT c = *reinterpret_cast<const IT *>(colidx + j);
-        VT v = *reinterpret_cast<const VT *>(val + j);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = j0 + u * SPMV_WG * E;
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const int jj = j + i;
             if (jj >= sb && jj < se)
-                acc = fmadd(v[i], xm1[c[i]], acc);
+                acc = fmadd(v[u][i], xv[u][i], acc);
         }
     }
     acc = group_sum<T, 64>(acc);

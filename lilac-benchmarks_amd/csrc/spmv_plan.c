@@ -235,6 +235,17 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
      * fail the builder's filler test and stay on STREAM.  Measured on NPB class C: STREAM 224 us,
      * TILED 122 us (bit-exact), STRIPED 82 us.
      */
+    /*
+     * Tiny matrices (a few dozen row blocks at most) are pure launch latency; one wavefront per
+     * row has no LDS phase and no barrier and finishes in 2.6 us where STREAM takes 4.0
+     * (NPB class S; profiles/r01_kbench20_dispatch_table.log).  Not with a row long enough to
+     * make one wave loop for microseconds.
+     */
+    if (st->nnz <= 131072 && st->rows <= 8192 && st->max_len <= 4096) {
+        *plan = SPMV_HIP_PLAN_VECTOR;
+        *param = 64;
+        return;
+    }
     const int W = SPMV_STRIPE_XBYTES / elem_size;
     const int S = cols > 0 ? (cols + W - 1) / W : 1;
     if (st->rows >= 32768 && cols >= W / 2 && S <= 128 && st->mean_len / (double)S >= 4.0) {

@@ -7,7 +7,7 @@ import pytest
 
 import matgen
 
-CAP, ROWCAP, SEG = 2044, 512, 16384
+CAP, ROWCAP, SEG = 2044, 512, 2048
 
 
 class StreamPlan(ctypes.Structure):
