@@ -196,6 +196,12 @@ int spmvd_copy_d2h_async(int device, void *dst, const void *src_dev, size_t byte
 int spmvd_stream_sync(int device);
 
 /* ---- misc ------------------------------------------------------------------- */
+/* Host threads for the one-time layout conversions (spmv_plan.c): fn(lo, hi, ctx) over [0, n) in
+ * contiguous chunks; SPMV_HIP_BUILD_THREADS overrides min(8, cores). */
+typedef void (*spmv_range_fn)(int64_t lo, int64_t hi, void *ctx);
+int spmv_build_threads(void);
+void spmv_parallel_for(int64_t n, int64_t grain, spmv_range_fn fn, void *ctx);
+
 void spmv_set_error(const char *fmt, ...);
 double spmv_now(void); /* seconds, CLOCK_MONOTONIC */
 

@@ -17,6 +17,9 @@
  */
 #include "spmv_internal.h"
 
+#include <pthread.h>
+#include <unistd.h>
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -212,6 +215,70 @@ void spmv_plan_bins_free(spmv_bin_plan *p)
 {
     free(p->bin_rows);
     memset(p, 0, sizeof *p);
+}
+
+/* ---- host threads for the one-time layout conversions ---------------------------------- */
+
+typedef struct par_task {
+    pthread_t th;
+    int64_t lo, hi;
+    spmv_range_fn fn;
+    void *ctx;
+} par_task;
+
+static void *par_entry(void *v)
+{
+    par_task *t = (par_task *)v;
+    t->fn(t->lo, t->hi, t->ctx);
+    return NULL;
+}
+
+int spmv_build_threads(void)
+{
+    static int n = 0;
+    if (n == 0) {
+        long cores = sysconf(_SC_NPROCESSORS_ONLN);
+        int want = cores > 8 ? 8 : (int)cores; /* memory-bound passes: more threads add nothing */
+        const char *e = getenv("SPMV_HIP_BUILD_THREADS");
+        if (e && atoi(e) > 0)
+            want = atoi(e);
+        n = want < 1 ? 1 : (want > 64 ? 64 : want);
+    }
+    return n;
+}
+
+/* fn(lo, hi, ctx) over [0, n) in contiguous chunks, one per thread; serial when n < 2 * grain or
+ * a thread cannot be started.  fn must not depend on how the range was cut. */
+void spmv_parallel_for(int64_t n, int64_t grain, spmv_range_fn fn, void *ctx)
+{
+    int nt = spmv_build_threads();
+    if (grain < 1)
+        grain = 1;
+    if (n / grain < nt)
+        nt = (int)(n / grain);
+    if (nt <= 1) {
+        if (n > 0)
+            fn(0, n, ctx);
+        return;
+    }
+    par_task task[64];
+    int started = 0;
+    for (int i = 0; i < nt; ++i) {
+        task[i].lo = n * i / nt;
+        task[i].hi = n * (i + 1) / nt;
+        task[i].fn = fn;
+        task[i].ctx = ctx;
+    }
+    for (int i = 1; i < nt; ++i) {
+        if (pthread_create(&task[i].th, NULL, par_entry, &task[i]) != 0)
+            break;
+        started = i;
+    }
+    fn(task[0].lo, task[0].hi, ctx);
+    for (int i = 1; i <= started; ++i)
+        pthread_join(task[i].th, NULL);
+    for (int i = started + 1; i < nt; ++i) /* threads that could not be started: do their share here */
+        fn(task[i].lo, task[i].hi, ctx);
 }
 
 /* ---- adaptive choice ------------------------------------------------------------ */

@@ -77,138 +77,217 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, int xbytes, int wp
     t->B = best_b;
 }
 
+/* ---- the conversion, in passes that split over host threads --------------------------------- */
+
+typedef struct build_ctx {
+    const void *a;
+    const int *rowstr, *colidx;
+    int r0, rows, cols, elem, S, W, B, WPB, EPL, G;
+    int64_t SUB;
+    int32_t *cnt;    /* [S][rows] entries of row r in stripe s                               */
+    int32_t *start;  /* [S][rows] position of the segment's first entry, relative to its stripe */
+    int64_t *sbase;  /* [S+1]     first position of each stripe                               */
+    int64_t *sdummy; /* [S]       fillers per stripe                                           */
+    int32_t *wlen;   /* [nw]      wave run lengths (whole sub-windows), then absolute via wptr */
+    spmv_striped_host *t;
+    volatile int bad; /* a column outside [1, cols] was seen */
+} build_ctx;
+
+/* pass 1, over rows: count the entries per (stripe, row) */
+static void pass_count(int64_t lo, int64_t hi, void *vc)
+{
+    build_ctx *c = (build_ctx *)vc;
+    for (int64_t r = lo; r < hi; ++r)
+        for (int j = c->rowstr[c->r0 + r] - 1; j < c->rowstr[c->r0 + r + 1] - 1; ++j) {
+            const int col = c->colidx[j] - 1;
+            if (col < 0 || col >= c->cols) {
+                c->bad = 1;
+                return;
+            }
+            c->cnt[(size_t)(col / c->W) * c->rows + r]++;
+        }
+}
+
+/* pass 2, over stripes: cut the rows of a stripe into B*WPB ranges of about equal entry counts and
+ * place every segment relative to the stripe's start (every wave streams whole sub-windows) */
+static void pass_layout(int64_t lo, int64_t hi, void *vc)
+{
+    build_ctx *c = (build_ctx *)vc;
+    const int rows = c->rows, parts = c->B * c->WPB;
+    for (int64_t s = lo; s < hi; ++s) {
+        const int32_t *cs = c->cnt + (size_t)s * rows;
+        int32_t *st = c->start + (size_t)s * rows;
+        int64_t stripe_entries = 0, dummies = 0;
+        for (int r = 0; r < rows; ++r)
+            stripe_entries += cs[r] > 0 ? cs[r] : 1;
+        int r = 0;
+        int64_t done = 0, total = 0;
+        for (int p = 0; p < parts; ++p) {
+            const int wi = (int)s * parts + p;
+            const int64_t wave_begin = total;
+            c->t->wrow[wi] = r;
+            const int64_t target = stripe_entries * (p + 1) / parts;
+            /* leave at least one row for every remaining part when possible */
+            while (r < rows && (done < target || p == parts - 1)) {
+                if (p < parts - 1 && rows - r <= parts - 1 - p)
+                    break;
+                const int n = cs[r] > 0 ? cs[r] : 1;
+                dummies += cs[r] == 0;
+                st[r] = (int32_t)total;
+                total += n;
+                done += n;
+                ++r;
+            }
+            total = (total + c->SUB - 1) / c->SUB * c->SUB;
+            c->wlen[wi] = (int32_t)(total - wave_begin);
+        }
+        c->sbase[s + 1] = total; /* turned into a running sum by the caller */
+        c->sdummy[s] = dummies;
+    }
+}
+
+/* pass 3, over rows: scatter in CSR order; a row's segments are touched by its own thread only */
+static void pass_scatter(int64_t lo, int64_t hi, void *vc)
+{
+    build_ctx *c = (build_ctx *)vc;
+    const int rows = c->rows, S = c->S, W = c->W, EPL = c->EPL, G = c->G;
+    const int64_t SUB = c->SUB;
+    int32_t *fill = (int32_t *)malloc((size_t)S * sizeof(int32_t));
+    if (!fill) {
+        c->bad = 2;
+        return;
+    }
+    uint16_t *tcol = c->t->col;
+    for (int64_t r = lo; r < hi; ++r) {
+        const int jb = c->rowstr[c->r0 + r] - 1, je = c->rowstr[c->r0 + r + 1] - 1;
+        if (jb == je)
+            continue;
+        memset(fill, 0, (size_t)S * sizeof(int32_t));
+        for (int j = jb; j < je; ++j) {
+            const int col = c->colidx[j] - 1;
+            const int s = col / W;
+            const size_t k = (size_t)s * rows + r;
+            const int64_t dst = c->sbase[s] + c->start[k] + fill[s]++;
+            uint16_t cc = (uint16_t)(col - s * W);
+            if (fill[s] == c->cnt[k])
+                cc |= 0x8000u; /* last entry of this row in this stripe */
+            tcol[dst] = cc;
+            /* values: lane-interleaved in 16-byte units inside each sub-window, so that lane l
+             * (entries l*EPL .. l*EPL+EPL-1) fetches them with dense 16-byte-per-lane loads */
+            const int64_t blk = dst / SUB * SUB, rr = dst % SUB;
+            const int64_t l = rr / EPL, i = rr % EPL;
+            const int64_t vdst = blk + (i / G) * (64 * G) + l * G + (i % G);
+            if (c->elem == 8)
+                ((double *)c->t->val)[vdst] = ((const double *)c->a)[j];
+            else
+                ((float *)c->t->val)[vdst] = ((const float *)c->a)[j];
+        }
+    }
+    free(fill);
+}
+
+/* pass 4, over stripes: the filler of an empty segment is a flag-only entry (value 0, column 0) */
+static void pass_fillers(int64_t lo, int64_t hi, void *vc)
+{
+    build_ctx *c = (build_ctx *)vc;
+    for (int64_t s = lo; s < hi; ++s) {
+        if (c->sdummy[s] == 0)
+            continue;
+        const int32_t *cs = c->cnt + (size_t)s * c->rows;
+        const int32_t *st = c->start + (size_t)s * c->rows;
+        for (int r = 0; r < c->rows; ++r)
+            if (cs[r] == 0)
+                c->t->col[c->sbase[s] + st[r]] = 0x8000u;
+    }
+}
+
 /*
  * rowstr / colidx / a: the caller's 1-based CSR; rows [r0,r1) are converted.
  * Returns 0, -1 (out of memory), -2 (not representable / not worth it).
+ * The result does not depend on the number of threads (SPMV_HIP_BUILD_THREADS).
  */
 int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,
                        int elem_size, int xbytes, int wpb, int target_wgs, int epl, spmv_striped_host *t)
 {
     const int rows = r1 - r0;
     spmv_striped_geometry(rows, cols, elem_size, xbytes, wpb, target_wgs, epl, t);
-    const int S = t->S, W = t->W, B = t->B, WPB = t->WPB;
-    const int64_t SUB = 64 * t->EPL;            /* entries per sub-window */
-    const int G = 16 / elem_size;               /* values per 16-byte unit */
+    const int S = t->S;
     if (rows <= 0 || (int64_t)S * rows > ((int64_t)1 << 28))
         return -2;
     const int64_t nnz = (int64_t)rowstr[r1] - rowstr[r0];
+    const int nw = S * t->B * t->WPB;
 
-    /* cnt[s*rows + r] = entries of row r in stripe s */
-    int32_t *cnt = (int32_t *)calloc((size_t)S * rows, sizeof(int32_t));
-    if (!cnt)
-        return -1;
-    for (int r = 0; r < rows; ++r)
-        for (int j = rowstr[r0 + r] - 1; j < rowstr[r0 + r + 1] - 1; ++j) {
-            const int c = colidx[j] - 1;
-            if (c < 0 || c >= cols) {
-                free(cnt);
-                return -2;
-            }
-            cnt[(size_t)(c / W) * rows + r]++;
-        }
-
-    const int nw = S * B * WPB;
+    build_ctx c;
+    memset(&c, 0, sizeof c);
+    c.a = a, c.rowstr = rowstr, c.colidx = colidx;
+    c.r0 = r0, c.rows = rows, c.cols = cols, c.elem = elem_size;
+    c.S = S, c.W = t->W, c.B = t->B, c.WPB = t->WPB, c.EPL = t->EPL;
+    c.G = 16 / elem_size;        /* values per 16-byte unit */
+    c.SUB = 64 * (int64_t)t->EPL; /* entries per sub-window */
+    c.t = t;
+    int rc = -1;
+    c.cnt = (int32_t *)calloc((size_t)S * rows, sizeof(int32_t));
+    c.start = (int32_t *)malloc((size_t)S * rows * sizeof(int32_t));
+    c.sbase = (int64_t *)calloc((size_t)S + 1, sizeof(int64_t));
+    c.sdummy = (int64_t *)calloc((size_t)S, sizeof(int64_t));
+    c.wlen = (int32_t *)calloc((size_t)nw + 1, sizeof(int32_t));
     t->n_waves = nw;
     t->wptr = (int32_t *)calloc((size_t)nw + 1, sizeof(int32_t));
     t->wrow = (int32_t *)calloc((size_t)nw + 1, sizeof(int32_t));
-    /* start[s*rows + r] = position of row r's first entry in stripe s (absolute) */
-    int32_t *start = (int32_t *)malloc((size_t)S * rows * sizeof(int32_t));
-    if (!t->wptr || !t->wrow || !start) {
-        free(cnt), free(start);
-        spmv_striped_free(t);
-        return -1;
+    if (!c.cnt || !c.start || !c.sbase || !c.sdummy || !c.wlen || !t->wptr || !t->wrow)
+        goto out;
+
+    spmv_parallel_for(rows, 4096, pass_count, &c);
+    if (c.bad) {
+        rc = -2;
+        goto out;
     }
+    spmv_parallel_for(S, 1, pass_layout, &c);
 
     int64_t total = 0, dummies = 0;
     for (int s = 0; s < S; ++s) {
-        const int32_t *cs = cnt + (size_t)s * rows;
-        int64_t stripe_entries = 0;
-        for (int r = 0; r < rows; ++r)
-            stripe_entries += cs[r] > 0 ? cs[r] : 1;
-        /* cut the rows into B*WPB ranges of about equal entry counts */
-        const int parts = B * WPB;
-        int r = 0;
-        int64_t done = 0;
-        for (int p = 0; p < parts; ++p) {
-            const int wi = s * parts + p;
-            total = (total + SUB - 1) / SUB * SUB; /* every wave streams whole sub-windows */
-            t->wptr[wi] = (int32_t)total;
-            t->wrow[wi] = r;
-            const int64_t target = stripe_entries * (p + 1) / parts;
-            /* leave at least one row for every remaining part when possible */
-            while (r < rows && (done < target || p == parts - 1)) {
-                if (p < parts - 1 && rows - r <= parts - 1 - p)
-                    break;
-                const int c = cs[r] > 0 ? cs[r] : 1;
-                dummies += cs[r] == 0;
-                start[(size_t)s * rows + r] = (int32_t)total;
-                total += c;
-                done += c;
-                ++r;
-                if (total > 0x7fffffff - 65536) {
-                    free(cnt), free(start);
-                    spmv_striped_free(t);
-                    return -2;
-                }
-            }
-        }
-        if (r != rows) { /* cannot happen: the last part takes everything left */
-            free(cnt), free(start);
-            spmv_striped_free(t);
-            return -2;
-        }
+        const int64_t len = c.sbase[s + 1];
+        c.sbase[s] = total;
+        total += len;
+        dummies += c.sdummy[s];
     }
-    total = (total + SUB - 1) / SUB * SUB;
-    t->wptr[nw] = (int32_t)total;
-    t->wrow[nw] = rows;
+    c.sbase[S] = total;
+    if (total > 0x7fffffff - 65536) {
+        rc = -2;
+        goto out;
+    }
+    {
+        int64_t pos = 0;
+        for (int wi = 0; wi < nw; ++wi) {
+            t->wptr[wi] = (int32_t)pos;
+            pos += c.wlen[wi];
+        }
+        t->wptr[nw] = (int32_t)pos; /* == total */
+        t->wrow[nw] = rows;
+    }
     t->n_packed = total;
     t->n_dummies = dummies;
     if (dummies * 8 > nnz) { /* more than 1/8 of the stream would be filler: the matrix is too
                                 sparse per stripe for this plan */
-        free(cnt), free(start);
-        spmv_striped_free(t);
-        return -2;
+        rc = -2;
+        goto out;
     }
 
-    const size_t n_alloc = (size_t)total + SPMV_TILE_PAD;
-    t->val = calloc(n_alloc, (size_t)elem_size);
-    t->col = (uint16_t *)calloc(n_alloc, sizeof(uint16_t));
-    if (!t->val || !t->col) {
-        free(cnt), free(start);
-        spmv_striped_free(t);
-        return -1;
+    {
+        const size_t n_alloc = (size_t)total + SPMV_TILE_PAD;
+        t->val = calloc(n_alloc, (size_t)elem_size);
+        t->col = (uint16_t *)calloc(n_alloc, sizeof(uint16_t));
+        if (!t->val || !t->col)
+            goto out;
     }
-    /* scatter in CSR order; `fill` counts the entries already placed per (stripe, row) */
-    int32_t *fill = (int32_t *)calloc((size_t)S * rows, sizeof(int32_t));
-    if (!fill) {
-        free(cnt), free(start);
+    spmv_parallel_for(rows, 1024, pass_scatter, &c);
+    if (c.bad)
+        goto out;
+    spmv_parallel_for(S, 1, pass_fillers, &c);
+    rc = 0;
+out:
+    free(c.cnt), free(c.start), free(c.sbase), free(c.sdummy), free(c.wlen);
+    if (rc != 0)
         spmv_striped_free(t);
-        return -1;
-    }
-    for (int r = 0; r < rows; ++r)
-        for (int j = rowstr[r0 + r] - 1; j < rowstr[r0 + r + 1] - 1; ++j) {
-            const int c = colidx[j] - 1;
-            const int s = c / W;
-            const size_t k = (size_t)s * rows + r;
-            const int64_t dst = (int64_t)start[k] + fill[k]++;
-            uint16_t cc = (uint16_t)(c - s * W);
-            if (fill[k] == cnt[k])
-                cc |= 0x8000u; /* last entry of this row in this stripe */
-            t->col[dst] = cc;
-            /* values: lane-interleaved in 16-byte units inside each sub-window, so that lane l
-             * (entries l*EPL .. l*EPL+EPL-1) fetches them with dense 16-byte-per-lane loads */
-            const int64_t blk = dst / SUB * SUB, rr = dst % SUB;
-            const int64_t l = rr / t->EPL, i = rr % t->EPL;
-            const int64_t vdst = blk + (i / G) * (64 * G) + l * G + (i % G);
-            if (elem_size == 8)
-                ((double *)t->val)[vdst] = ((const double *)a)[j];
-            else
-                ((float *)t->val)[vdst] = ((const float *)a)[j];
-        }
-    for (int s = 0; s < S; ++s)
-        for (int r = 0; r < rows; ++r)
-            if (cnt[(size_t)s * rows + r] == 0)
-                t->col[start[(size_t)s * rows + r]] = 0x8000u; /* dummy: value 0, flag only */
-    free(cnt), free(start), free(fill);
-    return 0;
+    return rc;
 }

@@ -1,6 +1,7 @@
 """Host-side planning (csrc/spmv_plan.c): row blocks, long-row segments, bins, GPU partition.
 Pure C, exercised through ctypes without a GPU."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -314,3 +315,39 @@ def test_striped_rejects_hypersparse(lib):
     rs, ci, a = matgen.sparsebench_like(3, 30)  # 27000 rows, ~5 per row over 27000 columns: 4 stripes, mostly dummies
     rc, _ = striped_emulate(lib, rs, ci, a, np.ones(27000))
     assert rc == -2
+
+
+_LAYOUT_HASH = r"""
+import sys, ctypes, hashlib, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import pkgload, matgen
+from test_plan import StripedHost
+pkg = pkgload.load_package()
+lib = ctypes.CDLL(pkg.lib_path())
+rs, ci, a = matgen.random_csr(77, 9000, 40000, 60)
+t = StripedHost()
+lib.spmv_striped_build.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 8 + [ctypes.POINTER(StripedHost)]
+assert lib.spmv_striped_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, 9000, 40000, 8, 65536, 8, 24, 4, ctypes.byref(t)) == 0
+h = hashlib.sha256()
+h.update(np.ctypeslib.as_array(t.col, (t.n_packed,)).tobytes())
+h.update(np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctypes.c_double)), (t.n_packed,)).tobytes())
+h.update(np.ctypeslib.as_array(t.wptr, (t.n_waves + 1,)).tobytes())
+h.update(np.ctypeslib.as_array(t.wrow, (t.n_waves + 1,)).tobytes())
+print(h.hexdigest(), t.n_packed, t.n_dummies)
+"""
+
+
+def test_striped_layout_does_not_depend_on_the_thread_count():
+    """The conversion runs its passes on host threads (SPMV_HIP_BUILD_THREADS); the layout, and with it
+    the order of every addition in k_striped, must be the same for any number of them."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _LAYOUT_HASH % (root, os.path.join(root, "tests"))
+    outs = []
+    for nt in ("1", "3", "8"):
+        env = dict(os.environ, SPMV_HIP_BUILD_THREADS=nt)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0].split()[0]) == 64
