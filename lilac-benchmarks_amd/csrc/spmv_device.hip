@@ -548,6 +548,15 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
         spmv_set_error("bad row range [%d,%d) of %d rows", row_begin, row_end, rows);
         return nullptr;
     }
+    if (rowstr[row_begin] < 1) {
+        spmv_set_error("rowstr[%d] = %d: row pointers are 1-based", row_begin, rowstr[row_begin]);
+        return nullptr;
+    }
+    for (int r = row_begin; r < row_end; ++r)
+        if (rowstr[r + 1] < rowstr[r]) {
+            spmv_set_error("rowstr decreases at row %d (%d -> %d)", r, rowstr[r], rowstr[r + 1]);
+            return nullptr;
+        }
     if (use_device(device))
         return nullptr;
     hipStream_t st = g_dev[device].stream;
@@ -592,23 +601,38 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
         FAIL();
     }
 
-    /* number of columns = max(colidx) over the whole matrix (libspmv/gpu.c:217-223) */
-    if (cols_hint > 0) {
-        m->cols = cols_hint;
-    } else if (row_begin == 0 && row_end == rows) {
-        int *d_max = nullptr;
-        HIPCHK(hipMalloc((void **)&d_max, sizeof(int)), FAIL());
-        HIPCHK(hipMemsetAsync(d_max, 0, sizeof(int), st), FAIL());
-        int rc = spmvk_colmax(m->d_col, m->nnz, d_max, st);
-        int h_max = 0;
-        hipError_t e1 = hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, st);
+    /*
+     * Column range of the block, by a device reduction over what was just uploaded.  The reference
+     * trusts the caller (an index < 1 reads before x, native-impl.c:9); on a GPU shared with other
+     * jobs an out-of-range gather can fault the device for everybody, so it is refused here.
+     */
+    int h_range[2] = {0, 0x7fffffff};
+    if (m->nnz > 0) {
+        int *d_range = nullptr;
+        HIPCHK(hipMalloc((void **)&d_range, 2 * sizeof(int)), FAIL());
+        hipError_t e0 = hipMemcpyAsync(d_range, h_range, sizeof h_range, hipMemcpyHostToDevice, st);
+        int rc = spmvk_colrange(m->d_col, m->nnz, d_range, st);
+        hipError_t e1 = hipMemcpyAsync(h_range, d_range, sizeof h_range, hipMemcpyDeviceToHost, st);
         hipError_t e2 = hipStreamSynchronize(st);
-        (void)hipFree(d_max);
-        if (rc || e1 != hipSuccess || e2 != hipSuccess) {
-            spmv_set_error("column-count reduction failed");
+        (void)hipFree(d_range);
+        if (rc || e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) {
+            spmv_set_error("column-range reduction failed");
             FAIL();
         }
-        m->cols = h_max;
+        if (h_range[1] < 1) {
+            spmv_set_error("column index %d < 1 (indices are 1-based)", h_range[1]);
+            FAIL();
+        }
+    }
+    /* number of columns = max(colidx) over the whole matrix (libspmv/gpu.c:217-223) */
+    if (cols_hint > 0) {
+        if (h_range[0] > cols_hint) {
+            spmv_set_error("column index %d beyond the %d columns announced", h_range[0], cols_hint);
+            FAIL();
+        }
+        m->cols = cols_hint;
+    } else if (row_begin == 0 && row_end == rows) {
+        m->cols = h_range[0];
     } else {
         const int64_t all = (int64_t)rowstr[rows] - rowstr[0];
         const int *c = colidx + (rowstr[0] - 1);

@@ -182,7 +182,8 @@ typedef struct spmv_dev_striped {
 } spmv_dev_striped;
 int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream);
 /* analysis: max(colidx[0..nnz)) -> *d_out (int, device), must be zeroed first */
-int spmvk_colmax(const int *colidx, int64_t nnz, int *d_out, void *stream);
+/* d_out[0] = max(colidx), d_out[1] = min(colidx); the caller presets {0, INT_MAX} */
+int spmvk_colrange(const int *colidx, int64_t nnz, int *d_out, void *stream);
 /* rowptr0[i] = rowstr[i] - rowstr[0] on device (in place allowed) */
 int spmvk_rebase(int *rowptr, int n_plus_1, int base, void *stream);
 

@@ -887,21 +887,26 @@ __global__ void __launch_bounds__(64) k_long_finish(const int *__restrict__ lrow
 }
 
 /* ================================ analysis ====================================== */
-__global__ void __launch_bounds__(SPMV_WG) k_colmax(const int *__restrict__ colidx, long long nnz,
-                                                    int *__restrict__ out)
+__global__ void __launch_bounds__(SPMV_WG) k_colrange(const int *__restrict__ colidx, long long nnz,
+                                                       int *__restrict__ out /* [0] max, [1] min */)
 {
-    int m = 0;
+    int m = 0, n = 0x7fffffff;
     for (long long j = (long long)blockIdx.x * SPMV_WG + threadIdx.x; j < nnz;
          j += (long long)gridDim.x * SPMV_WG) {
         int c = colidx[j];
         m = c > m ? c : m;
+        n = c < n ? c : n;
     }
     for (int o = 32; o; o >>= 1) {
         int t = __shfl_xor(m, o, 64);
         m = t > m ? t : m;
+        t = __shfl_xor(n, o, 64);
+        n = t < n ? t : n;
     }
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
         atomicMax(out, m);
+        atomicMin(out + 1, n);
+    }
 }
 
 __global__ void __launch_bounds__(SPMV_WG) k_rebase(int *__restrict__ rowptr, int n, int base)
@@ -1143,13 +1148,13 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
     return launch_status();
 }
 
-int spmvk_colmax(const int *colidx, int64_t nnz, int *d_out, void *stream)
+int spmvk_colrange(const int *colidx, int64_t nnz, int *d_out, void *stream)
 {
     if (nnz <= 0)
         return 0;
     long long want = (nnz + SPMV_WG - 1) / SPMV_WG;
     int grid = (int)(want < 2048 ? want : 2048);
-    hipLaunchKernelGGL(k_colmax, dim3(grid), dim3(SPMV_WG), 0, (hipStream_t)stream, colidx,
+    hipLaunchKernelGGL(k_colrange, dim3(grid), dim3(SPMV_WG), 0, (hipStream_t)stream, colidx,
                        (long long)nnz, d_out);
     return launch_status();
 }

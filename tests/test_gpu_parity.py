@@ -530,3 +530,32 @@ def test_graph_callers_at_scale(pkg, backend, oracle):
     x1, e1 = C.pagerank(g, backend.harness_fn(), 10, prepare=False)
     assert np.all(np.abs(x0 - x1) <= 1e-12 * np.abs(x0).max()) and abs(e0 - e1) <= 1e-10
     C.free(g)
+
+
+def test_malformed_matrices_are_refused_before_any_kernel_runs(backend):
+    """An index outside x would be a stray read in native-impl.c:9; on the GPU it can fault the device,
+    so the upload refuses it (and the ABI path turns the refusal into message + abort, like gpu.c's asserts)."""
+    rs, ci, a = matgen.random_csr(5, 300, 300, 7)
+    bad = ci.copy()
+    bad[17] = 0
+    with pytest.raises(RuntimeError, match="column index 0 < 1"):
+        backend.matrix(a, rs, bad, 300)
+    bad[17] = -5
+    with pytest.raises(RuntimeError, match="< 1"):
+        backend.matrix(a, rs, bad, 300)
+    with pytest.raises(RuntimeError, match="beyond the 100 columns"):
+        backend.matrix(a, rs, ci, 300, cols_hint=100)
+    rs2 = rs.copy()
+    rs2[40] = rs2[39] - 1
+    with pytest.raises(RuntimeError, match="rowstr decreases at row 39"):
+        backend.matrix(a, rs2, ci, 300)
+    rs3 = rs - 1  # 0-based row pointers
+    with pytest.raises(RuntimeError, match="1-based"):
+        backend.matrix(a, rs3, ci, 300)
+    env = dict(os.environ, SPMV_HIP_LIB=backend.path)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import numpy as np, pkgload, matgen;"
+            "pkg = pkgload.load_package(); be = pkg.Backend(); rs, ci, a = matgen.random_csr(5, 300, 300, 7);"
+            "ci[3] = 0; y = np.zeros(300); be.harness(y, a, np.ones(300), rs, ci, 300)") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == -6 and "column index 0 < 1" in r.stderr  # SIGABRT with the diagnostic
