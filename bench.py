@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered|tiled|striped")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-npb", action="store_true", help="skip the full NPB CG run through the ABI")
-    ap.add_argument("--cpu-iters", type=int, default=3, help="timed CG iterations of the CPU sample")
+    ap.add_argument("--cpu-iters", type=int, default=10, help="timed CG iterations of the CPU sample")
     ap.add_argument("--npb-repeats", type=int, default=5, help="runs of the full NPB CG benchmark; the median is reported")
     args = ap.parse_args()
 
