@@ -22,6 +22,8 @@ gives the per-launch duration for the roofline object.  Rank 0 at N = 1 addition
   * npb_cg: the complete NPB CG class C benchmark through the drop-in ABI (host vectors, PCIe
     round trip of x and y on each of its 1976 SpMV calls) -> MOp/s by cg.f:395-402, verified
     against cg.f:122-163;
+  * scale_ref: class D (the N > 1 workload) on this one GPU, the like-for-like first point of the
+    strong-scaling series;
   * cpu_baseline: the reference's CPU path (oracle/_ref/native.so when it was built in the
     authoring container, else our port) on one host core, on a bounded sample.
 """
@@ -62,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-npb", action="store_true", help="skip the full NPB CG run through the ABI")
     ap.add_argument("--cpu-iters", type=int, default=10, help="timed CG iterations of the CPU sample")
+    ap.add_argument("--no-scale-ref", action="store_true", help="skip the class D single-GPU reference point at N=1")
     ap.add_argument("--npb-repeats", type=int, default=5, help="runs of the full NPB CG benchmark; the median is reported")
     args = ap.parse_args()
 
@@ -231,9 +234,36 @@ def main():
             "repeats": len(runsd), "mops_all": [round(r["mops"], 1) for r in runsd],
             "verified_all": all(bool(r["verified"]) for r in runsd),
             "zeta": resd["zeta"], "err": resd["err"], "verified": bool(resd["verified"]),
-            "path": "spmv_hip_cg_* opt-in entry points: p,q,r,z,x resident in HBM, 5 kernels per CG iteration, "
+            "path": "spmv_hip_cg_* opt-in entry points: p,q,r,z,x resident in HBM, 4 kernels per CG iteration (p.q folded into the SpMV), "
                     "host sees two norms per outer iteration",
         }
+
+    if rank == 0 and n_gpus == 1 and cls == "C" and not args.no_scale_ref:
+        # the workload of the N > 1 runs (class D, BASELINE configs[4]) on this one GPU, whole matrix:
+        # the like-for-like 1-GPU point for the strong-scaling series (the headline above stays class C)
+        t0 = time.time()
+        md = pkg.npb.NpbMatrix("D")
+        t_gen = time.time() - t0
+        dmd = be.matrix(md.a, md.rowstr, md.colidx, md.rows, device=device, cols_hint=md.na)
+        infd = dmd.info()
+        xd = np.random.default_rng(12345).standard_normal(md.na + 2)
+        dxd = be.malloc(xd.nbytes, device)
+        dyd = be.malloc(md.rows * 8, device)
+        be.h2d(dxd, xd, device)
+        dmd.time_device(dxd, dyd, 3)
+        ksteps = 20
+        msd = dmd.time_device(dxd, dyd, ksteps) / ksteps
+        line["scale_ref"] = {
+            "workload": "NPB CG class D, whole matrix on 1 GPU (what the N > 1 runs partition)",
+            "value": round(2.0 * md.nnz / (msd * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "ms_per_step": round(msd, 6),
+            "steps": ksteps, "nnz": int(md.nnz), "plan": pkg.abi.PLAN_NAMES[infd["plan"]],
+            "roofline_frac": round(infd["algorithmic_bytes"] / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": infd["algorithmic_bytes"], "generated_s": round(t_gen, 1),
+        }
+        dmd.close()
+        be.free(dxd, device)
+        be.free(dyd, device)
+        md.close()
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu:
         from oracle import oracle as orc  # checker / baseline only

@@ -9,7 +9,7 @@
  * that does not know them loses nothing.
  *
  * One CG iteration (cg.f:513-620) = SpMV (q = A p) + three vector kernels, no host sync:
- *   k_dot      d_part[b]   = sum over block b of p*q
+ *   k_dot      d_part[b]   = sum over block b of p*q   (folded into k_stripe_sum under the STRIPED plan)
  *   k_axpy     alpha = rho/d with rho = sum(rho_part_prev), d = sum(d_part) (every block adds the
  *              ~150 partials itself, in index order);  z += alpha p;  r -= alpha q;
  *              rho_part_new[b] = sum over block b of r*r
@@ -44,10 +44,16 @@ __device__ __forceinline__ double block_sum(double v, double *s_w)
 
 __device__ __forceinline__ double sum_partials(const double *__restrict__ part, int nb)
 {
-    /* every thread adds the same nb values in the same order: a broadcast read pattern */
+    /* Every wave of every block needs the same scalar, bit for bit: lane l adds part[l], part[l+64],
+     * ... in that order, then a butterfly over the wave -- the same tree in every lane (a + b and
+     * b + a are the same double), so all lanes of all waves end with one value.  A plain loop over
+     * the ~150 partials was a 150-deep dependent chain and cost 15 us per kernel. */
+    const int lane = threadIdx.x & 63;
     double s = 0.0;
-    for (int i = 0; i < nb; ++i)
+    for (int i = lane; i < nb; i += 64)
         s += part[i];
+    for (int o = 32; o; o >>= 1)
+        s += __shfl_xor(s, o, 64);
     return s;
 }
 
@@ -105,11 +111,11 @@ __global__ void __launch_bounds__(256) k_cg_axpy(double *__restrict__ z, double 
                                                  const double *__restrict__ p, const double *__restrict__ q,
                                                  const double *__restrict__ rho_part,
                                                  const double *__restrict__ d_part,
-                                                 double *__restrict__ rho_new_part, int n, int nb)
+                                                 double *__restrict__ rho_new_part, int n, int nb, int nd)
 {
     __shared__ double s_w[4];
     const double rho = sum_partials(rho_part, nb);
-    const double d = sum_partials(d_part, nb);
+    const double d = sum_partials(d_part, nd);
     const double alpha = rho / d;
     double acc = 0.0;
     for (int k = 0; k < 4; ++k) {
@@ -232,7 +238,8 @@ spmv_hip_cg *spmv_hip_cg_create(spmv_hip_matrix *m)
     for (double **v : vecs)
         ok = ok && hipMalloc((void **)v, vb) == hipSuccess && hipMemset(*v, 0, vb) == hipSuccess;
     for (int k = 0; k < 4; ++k)
-        ok = ok && hipMalloc((void **)&c->part[k], ((size_t)c->nb + 1) * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&c->part[k], ((size_t)(c->n + SPMV_WG - 1) / SPMV_WG + 1) * sizeof(double)) ==
+                       hipSuccess; /* room for one partial per 256 rows (the folded dot), nb <= that */
     ok = ok && hipHostMalloc((void **)&c->h_part, (size_t)(2 * c->nb + 2) * sizeof(double), hipHostMallocDefault) ==
                    hipSuccess;
     if (!ok) {
@@ -281,12 +288,20 @@ int spmv_hip_cg_conj_grad(spmv_hip_cg *c, int cgitmax, double *rnorm)
     double *rho_prev = c->part[0], *rho_new = c->part[1], *dpart = c->part[2];
     hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(256), 0, st, c->x, c->z, c->p, c->q, c->r, rho_prev, n);
     for (int it = 0; it < cgitmax; ++it) {
-        if (spmv_hip_spmv_device(c->m, c->p, c->q, st)) /* q = A p, cg.f:532 */
+        /* q = A p (cg.f:532) and d = p.q (cg.f:573-577): the STRIPED plan leaves the block partials of
+         * the dot behind in the kernel that writes q; other plans get a separate pass over q */
+        int nd = spmvd_spmv_dot(c->m, c->p, c->q, st, c->p, dpart);
+        if (nd < 0)
             return -1;
-        hipLaunchKernelGGL(k_cg_dot, dim3(nb), dim3(256), 0, st, c->p, c->q, dpart, (const double *)nullptr,
-                           (const double *)nullptr, (double *)nullptr, n);
+        if (nd == 0) {
+            if (spmv_hip_spmv_device(c->m, c->p, c->q, st))
+                return -1;
+            hipLaunchKernelGGL(k_cg_dot, dim3(nb), dim3(256), 0, st, c->p, c->q, dpart, (const double *)nullptr,
+                               (const double *)nullptr, (double *)nullptr, n);
+            nd = nb;
+        }
         hipLaunchKernelGGL(k_cg_axpy, dim3(nb), dim3(256), 0, st, c->z, c->r, c->p, c->q, rho_prev, dpart, rho_new,
-                           n, nb);
+                           n, nb, nd);
         hipLaunchKernelGGL(k_cg_pupd, dim3(nb), dim3(256), 0, st, c->p, c->r, rho_new, rho_prev, n, nb);
         double *t = rho_prev;
         rho_prev = rho_new;

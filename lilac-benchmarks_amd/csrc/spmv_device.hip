@@ -797,6 +797,27 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     return 0;
 }
 
+/*
+ * y = A x and, in the same launches, the block partials of y . v (spmv_cg.hip: q = A p and p.q of a
+ * CG step).  Only the STRIPED plan can fold the dot into its last kernel; returns the number of
+ * partials written to dot_part (one per 256 rows), 0 when the plan cannot (the caller then runs its
+ * own dot over y), -1 on error.
+ */
+int spmvd_spmv_dot(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream, const void *v_dev,
+                   void *dot_part)
+{
+    if (!m || m->rows == 0 || m->plan != SPMV_HIP_PLAN_STRIPED || (reinterpret_cast<uintptr_t>(x_dev) & 15u) != 0)
+        return 0;
+    HIPCHK(hipSetDevice(m->device), return -1);
+    hipStream_t st = stream_of(m->device, stream);
+    int rc = spmvk_striped(&m->ds, x_dev, y_dev, st, v_dev, dot_part);
+    if (rc) {
+        spmv_set_error("kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return -1;
+    }
+    return (m->rows + SPMV_WG - 1) / SPMV_WG;
+}
+
 int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream)
 {
     if (!m)
@@ -819,7 +840,7 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
     case SPMV_HIP_PLAN_TILED:
         if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0) {
             rc = m->plan == SPMV_HIP_PLAN_TILED ? spmvk_tiled(&m->dt, x_dev, y_dev, st)
-                                                : spmvk_striped(&m->ds, x_dev, y_dev, st);
+                                                : spmvk_striped(&m->ds, x_dev, y_dev, st, nullptr, nullptr);
             break;
         }
         /* k_tiled stages x with 16-byte loads; a misaligned x goes to the row-segment kernel */

@@ -180,7 +180,15 @@ typedef struct spmv_dev_striped {
     int elem, W, S, WPB, B, EPL, rows, cols;
     int xbytes; /* LDS stripe capacity (65536 / 131072) the layout was built for */
 } spmv_dev_striped;
-int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream);
+struct spmv_hip_matrix;
+/* y = A x plus block partials of y . v when the plan can fold them in (STRIPED): returns the number
+ * of partials (one per 256 rows), 0 = not folded (run a separate dot), -1 = error */
+int spmvd_spmv_dot(struct spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream, const void *v_dev,
+                   void *dot_part);
+
+/* dotv != NULL: also dot_part[b] = sum over rows [256 b, 256 b + 256) of y[r] * dotv[r] */
+int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream, const void *dotv,
+                  void *dot_part);
 /* analysis: max(colidx[0..nnz)) -> *d_out (int, device), must be zeroed first */
 /* d_out[0] = max(colidx), d_out[1] = min(colidx); the caller presets {0, INT_MAX} */
 int spmvk_colrange(const int *colidx, int64_t nnz, int *d_out, void *stream);

@@ -787,28 +787,43 @@ done:
         out[flushed + (unsigned int)lane] = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
 }
 
+/* y[r] = sum of the S partial sums of row r, in stripe order.  With `dotv` the kernel also leaves
+ * dot_part[block] = sum over the block's rows of y[r] * dotv[r] (fixed order: wave butterfly, then the
+ * four waves in order) -- the p.q of a CG step without another pass over y (spmv_cg.hip). */
 template <typename T>
 __global__ void __launch_bounds__(SPMV_WG) k_stripe_sum(const T *__restrict__ partial, T *__restrict__ y,
-                                                        int rows, int S)
+                                                        int rows, int S, const T *__restrict__ dotv,
+                                                        T *__restrict__ dot_part)
 {
     const int r = blockIdx.x * SPMV_WG + threadIdx.x;
-    if (r >= rows)
-        return;
-    const T *p = partial + r;
     T acc = (T)0;
-    int s = 0;
-    for (; s + 8 <= S; s += 8) { /* eight loads in flight, added in stripe order */
-        T v[8];
+    if (r < rows) {
+        const T *p = partial + r;
+        int s = 0;
+        for (; s + 8 <= S; s += 8) { /* eight loads in flight, added in stripe order */
+            T v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            v[k] = p[(size_t)(s + k) * rows];
+            for (int k = 0; k < 8; ++k)
+                v[k] = p[(size_t)(s + k) * rows];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            acc = acc + v[k];
+            for (int k = 0; k < 8; ++k)
+                acc = acc + v[k];
+        }
+        for (; s < S; ++s)
+            acc = acc + p[(size_t)s * rows];
+        y[r] = acc;
     }
-    for (; s < S; ++s)
-        acc = acc + p[(size_t)s * rows];
-    y[r] = acc;
+    if (dotv) { /* kernel-uniform */
+        __shared__ T s_w[SPMV_WG / 64];
+        T d = r < rows ? acc * dotv[r] : (T)0;
+        for (int o = 32; o; o >>= 1)
+            d += __shfl_xor(d, o, 64);
+        if ((threadIdx.x & 63) == 0)
+            s_w[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            dot_part[blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+    }
 }
 
 /* ================================ k_long ======================================== */
@@ -1084,7 +1099,8 @@ int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream)
     return launch_status();
 }
 
-int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream)
+int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream, const void *dotv,
+                  void *dot_part)
 {
     hipStream_t st = (hipStream_t)stream;
     if (t->rows <= 0)
@@ -1141,10 +1157,12 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
 #undef SPMV_LS2
     if (t->elem == 8)
         hipLaunchKernelGGL(k_stripe_sum<double>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
-                           (const double *)t->partial, (double *)y, t->rows, t->S);
+                           (const double *)t->partial, (double *)y, t->rows, t->S, (const double *)dotv,
+                           (double *)dot_part);
     else
         hipLaunchKernelGGL(k_stripe_sum<float>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
-                           (const float *)t->partial, (float *)y, t->rows, t->S);
+                           (const float *)t->partial, (float *)y, t->rows, t->S, (const float *)dotv,
+                           (float *)dot_part);
     return launch_status();
 }
 
