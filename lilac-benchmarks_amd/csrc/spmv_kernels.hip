@@ -624,13 +624,32 @@ __device__ __forceinline__ void stripe_load(StripeRegs<T, EPL> &r, const T *__re
         r.v[j] = *reinterpret_cast<const VT *>(pval + base + (unsigned int)(j * 64 * E) + (unsigned int)lane * E);
 }
 
+/*
+ * A global store the compiler's wait-count bookkeeping does not see.  gfx950 has one counter
+ * (vmcnt) for vector loads AND stores; with a data-dependent number of stores in the loop the
+ * compiler can no longer tell how many operations are younger than a load, and waits vmcnt(0)
+ * before every use -- which also drains the loads of the NEXT register set and collapses the
+ * ring to depth one.  The partial sums written here are never read back by this kernel, so the
+ * store needs no wait at all; counting only the loads, the compiler's vmcnt(N) stays correct
+ * (loads return in order among themselves: once N + #stores operations remain outstanding at
+ * most, with at most #stores of them stores, the load being waited for is back).
+ */
+__device__ __forceinline__ void store_untracked(double *p, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_untracked(float *p, float v)
+{
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
 template <typename T, int WPB, int R, int XT_BYTES, int EPL>
 __global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__ wptr,
                                                          const int *__restrict__ wrow,
                                                          const unsigned short *__restrict__ pcol,
                                                          const T *__restrict__ pval,
                                                          const T *__restrict__ x, T *__restrict__ partial,
-                                                         int rows, int cols, int B, int wcols, int dbg)
+                                                         int rows, int cols, int B, int wcols)
 {
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E;
@@ -688,100 +707,108 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__
     unsigned int flushed = row;
     auto flush64 = [&]() {
         const T v = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
-        out[flushed + (unsigned int)lane] = v;
+        store_untracked(out + (flushed + (unsigned int)lane), v);
         flushed += 64;
     };
-    for (int jj = 0;; jj += R) {
+    /*
+     * One sub-window.  The main loop below calls this R times per trip with no exit in between, so
+     * the R register sets stay a static ring (no copies, and the compiler can count the loads in
+     * flight: it waits for exactly the set it consumes); the last nsub % R sub-windows run after the
+     * loop, without reloading.
+     */
+    auto sub_window = [&](StripeRegs<T, EPL> &regs, const int sb, const bool reload)
+                          __attribute__((always_inline)) {
+        T p[EPL];
+        int f[EPL];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int sb = P0 + (jj + r) * SUB;
-            if (sb >= P1)
-                goto done;
-            T p[EPL];
-            int f[EPL];
-#pragma unroll
-            for (int k = 0; k < EPL; ++k) {
-                const unsigned int c = set[r].col(k);
-                p[k] = set[r].val(k) * ((dbg & 4) ? (T)c : s_x[c & (W - 1)]);
-                f[k] = (int)(c >> 15);
-            }
-            stripe_load<T, EPL>(set[r], pval, pcol, sb + R * SUB, lane);
-            /* lane-local: the sum after the lane's last row end, and whether it has a row end */
-            T tailv = (T)0;
-            int has = 0;
-#pragma unroll
-            for (int k = 0; k < EPL; ++k) {
-                tailv = tailv + p[k]; /* the flagged entry itself still belongs to the closing row */
-                if (f[k])
-                    tailv = (T)0;
-                has |= f[k];
-            }
-            /* inclusive segmented scan of (tailv, has) over the wave */
-            T sv = tailv;
-            int sf = has;
-            if (!(dbg & 2)) {
-                segscan_step<T, 0x111, 0xf>(sv, sf); /* row_shr:1 */
-                segscan_step<T, 0x112, 0xf>(sv, sf); /* row_shr:2 */
-                segscan_step<T, 0x114, 0xf>(sv, sf); /* row_shr:4 */
-                segscan_step<T, 0x118, 0xf>(sv, sf); /* row_shr:8 */
-                segscan_step<T, 0x142, 0xa>(sv, sf); /* row_bcast:15 */
-                segscan_step<T, 0x143, 0xc>(sv, sf); /* row_bcast:31 */
-            }
-            if (!sf)
-                sv = sv + carry; /* no row end at or before this lane: the previous sub-window's open sum */
-            T cin = dpp_mov<0x138, 0xf>(sv); /* wave_shr:1: what the lane below leaves open */
-            if (lane == 0)
-                cin = carry;
-            carry = __shfl(sv, 63, 64);
-
-            /* row numbers: count the row ends in lower lanes */
-            unsigned int before = 0, nflags = 0;
-#pragma unroll
-            for (int k = 0; k < EPL; ++k) {
-                const unsigned long long m = __ballot(f[k] != 0);
-                before += __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0));
-                nflags += (unsigned int)__builtin_popcountll(m);
-            }
-            /* emit the rows that end in this lane */
-            T run = cin;
-            unsigned int idx = row + before;
-            if (nflags <= RING - 64) { /* wave-uniform; the ring holds < 64 pending rows here */
-#pragma unroll
-                for (int k = 0; k < EPL; ++k) {
-                    run = run + p[k];
-                    if (f[k]) {
-                        s_out[w][idx & (RING - 1)] = run;
-                        ++idx;
-                        run = (T)0;
-                    }
-                }
-                row += nflags;
-                __builtin_amdgcn_wave_barrier();
-                while (row - flushed >= 64u)
-                    if (!(dbg & 1))
-                        flush64();
-                    else
-                        flushed += 64;
-                __builtin_amdgcn_wave_barrier();
-            } else { /* a sub-window crowded with tiny rows: drain the ring, then store directly */
-                if ((unsigned int)lane < row - flushed)
-                    out[flushed + (unsigned int)lane] = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
-#pragma unroll
-                for (int k = 0; k < EPL; ++k) {
-                    run = run + p[k];
-                    if (f[k]) {
-                        out[idx] = run;
-                        ++idx;
-                        run = (T)0;
-                    }
-                }
-                row += nflags;
-                flushed = row;
-            }
+        for (int k = 0; k < EPL; ++k) {
+            const unsigned int c = regs.col(k);
+            p[k] = regs.val(k) * s_x[c & (W - 1)];
+            f[k] = (int)(c >> 15);
         }
+        if (reload) /* compile-time at every call site */
+            stripe_load<T, EPL>(regs, pval, pcol, sb + R * SUB, lane);
+        /* lane-local: the sum after the lane's last row end, and whether it has a row end */
+        T tailv = (T)0;
+        int has = 0;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            tailv = tailv + p[k]; /* the flagged entry itself still belongs to the closing row */
+            if (f[k])
+                tailv = (T)0;
+            has |= f[k];
+        }
+        /* inclusive segmented scan of (tailv, has) over the wave */
+        T sv = tailv;
+        int sf = has;
+        segscan_step<T, 0x111, 0xf>(sv, sf); /* row_shr:1 */
+        segscan_step<T, 0x112, 0xf>(sv, sf); /* row_shr:2 */
+        segscan_step<T, 0x114, 0xf>(sv, sf); /* row_shr:4 */
+        segscan_step<T, 0x118, 0xf>(sv, sf); /* row_shr:8 */
+        segscan_step<T, 0x142, 0xa>(sv, sf); /* row_bcast:15 */
+        segscan_step<T, 0x143, 0xc>(sv, sf); /* row_bcast:31 */
+        if (!sf)
+            sv = sv + carry; /* no row end at or before this lane: the previous sub-window's open sum */
+        T cin = dpp_mov<0x138, 0xf>(sv); /* wave_shr:1: what the lane below leaves open */
+        if (lane == 0)
+            cin = carry;
+        carry = __shfl(sv, 63, 64);
+
+        /* row numbers: count the row ends in lower lanes */
+        unsigned int before = 0, nflags = 0;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const unsigned long long m = __ballot(f[k] != 0);
+            before += __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32),
+                                                __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0));
+            nflags += (unsigned int)__builtin_popcountll(m);
+        }
+        /* emit the rows that end in this lane */
+        T run = cin;
+        unsigned int idx = row + before;
+        if (nflags <= RING - 64) { /* wave-uniform; the ring holds < 64 pending rows here */
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                run = run + p[k];
+                if (f[k]) {
+                    s_out[w][idx & (RING - 1)] = run;
+                    ++idx;
+                    run = (T)0;
+                }
+            }
+            row += nflags;
+            __builtin_amdgcn_wave_barrier();
+            while (row - flushed >= 64u)
+                flush64();
+            __builtin_amdgcn_wave_barrier();
+        } else { /* a sub-window crowded with tiny rows: drain the ring, then store directly */
+            if ((unsigned int)lane < row - flushed)
+                store_untracked(out + (flushed + (unsigned int)lane),
+                                s_out[w][(flushed + (unsigned int)lane) & (RING - 1)]);
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                run = run + p[k];
+                if (f[k]) {
+                    store_untracked(out + idx, run);
+                    ++idx;
+                    run = (T)0;
+                }
+            }
+            row += nflags;
+            flushed = row;
+        }
+    };
+    const int nsub = (P1 - P0) / SUB;
+    int j = 0;
+    for (; j + R <= nsub; j += R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            sub_window(set[r], P0 + (j + r) * SUB, true);
     }
-done:
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r)
+        if (j + r < nsub) /* wave-uniform */
+            sub_window(set[r], P0 + (j + r) * SUB, false);
     __builtin_amdgcn_wave_barrier();
     if ((unsigned int)lane < row - flushed) /* the last < 64 rows of the wave's range */
         out[flushed + (unsigned int)lane] = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
@@ -1109,7 +1136,7 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
 #define SPMV_LS2(T, WPB, R, XT, EPL)                                                                   \
     hipLaunchKernelGGL((k_striped<T, WPB, R, XT, EPL>), dim3(grid), dim3(WPB * 64), 0, st, t->wptr,    \
                        t->wrow, t->col, (const T *)t->val, (const T *)x, (T *)t->partial, t->rows,     \
-                       t->cols, t->B, t->W, g_tune_tile_dbg)
+                       t->cols, t->B, t->W)
 #define SPMV_LS2R(T, WPB, XT, EPL)                                                                     \
     do {                                                                                               \
         if (g_tune_tile_k == 4)                                                                        \
