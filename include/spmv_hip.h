@@ -29,8 +29,10 @@ enum {
     SPMV_HIP_PLAN_TILED = 5,   /* column stripes of x held in LDS, one row per lane; sums each  */
                                /* row stripe by stripe in stored order: bit-identical to the    */
                                /* reference when a row's columns are sorted                     */
-    SPMV_HIP_PLAN_STRIPED = 6  /* 2-D: a workgroup keeps one stripe of x in LDS for its whole    */
+    SPMV_HIP_PLAN_STRIPED = 6, /* 2-D: a workgroup keeps one stripe of x in LDS for its whole    */
                                /* life; per-(stripe,row) partial sums added in stripe order      */
+    SPMV_HIP_PLAN_LANES = 7    /* the same 2-D decomposition with whole (row,stripe) segments     */
+                               /* dealt to lanes: one FMA per entry, no cross-lane work          */
 };
 
 /* Opaque device-resident matrix (CSR block + execution plan) on one GPU. */

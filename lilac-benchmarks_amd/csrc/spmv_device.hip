@@ -110,6 +110,11 @@ struct spmv_hip_matrix {
     bool striped_mostly_filler = false;
     int striped_rc = 0;
     spmv_dev_striped ds{};
+    /* LANES (built on demand) */
+    bool have_lanes = false;
+    bool lanes_mostly_pad = false;
+    int lanes_rc = 0;
+    spmv_dev_lanes dl{};
 };
 
 extern "C" {
@@ -269,6 +274,15 @@ static void free_plans(spmv_hip_matrix *m)
         (void)hipFree((void *)m->ds.val);
         (void)hipFree(m->ds.partial);
         m->have_striped = false;
+    }
+    if (m->have_lanes) {
+        (void)hipFree((void *)m->dl.wptr);
+        (void)hipFree((void *)m->dl.wslot);
+        (void)hipFree((void *)m->dl.islot);
+        (void)hipFree((void *)m->dl.col);
+        (void)hipFree((void *)m->dl.val);
+        (void)hipFree(m->dl.partial);
+        m->have_lanes = false;
     }
     if (m->have_tiled) {
         (void)hipFree((void *)m->dt.wptr);
@@ -536,6 +550,117 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     return 0;
 }
 
+/* LANES: same flow as ensure_striped (host_a == nullptr: fetch the CSR arrays back from the device) */
+static int ensure_lanes(spmv_hip_matrix *m, const void *host_a, const int *host_col, int64_t first, bool auto_choice)
+{
+    if (m->have_lanes) {
+        if (auto_choice && m->lanes_mostly_pad) {
+            m->lanes_rc = -2;
+            return -2;
+        }
+        return 0;
+    }
+    void *tmp_a = nullptr;
+    int *tmp_c = nullptr;
+    if (!host_a) {
+        tmp_a = malloc((size_t)(m->nnz ? m->nnz : 1) * m->elem);
+        tmp_c = (int *)malloc((size_t)(m->nnz ? m->nnz : 1) * sizeof(int));
+        if (!tmp_a || !tmp_c) {
+            free(tmp_a), free(tmp_c);
+            spmv_set_error("out of host memory for the LANES conversion");
+            return -1;
+        }
+        hipStream_t st = g_dev[m->device].stream;
+        if (m->nnz > 0) {
+            HIPCHK(hipMemcpyAsync(tmp_a, m->d_val, (size_t)m->nnz * m->elem, hipMemcpyDeviceToHost, st),
+                   { free(tmp_a); free(tmp_c); return -1; });
+            HIPCHK(hipMemcpyAsync(tmp_c, m->d_col, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost, st),
+                   { free(tmp_a); free(tmp_c); return -1; });
+        }
+        HIPCHK(hipStreamSynchronize(st), { free(tmp_a); free(tmp_c); return -1; });
+        host_a = tmp_a;
+        host_col = tmp_c;
+        first = 0;
+    }
+    const int64_t shift = first - ((int64_t)m->h_rowstr_local[0] - 1);
+    spmv_lanes_host th;
+    const int wpb = g_stripe_wpb == 8 && g_stripe_xbytes == 65536 ? 8 : 16; /* the instantiated shapes */
+    int rc = m->cols < 16 ? -2
+                          : spmv_lanes_build((const char *)host_a + shift * m->elem, m->h_rowstr_local,
+                                             host_col + shift, 0, m->rows, m->cols, m->elem, g_stripe_xbytes, wpb,
+                                             g_stripe_wgs, &th);
+    free(tmp_a), free(tmp_c);
+    /* padding beyond 1/8 of the nonzeros: the lanes of a wave are too uneven (few rows per wave, or
+     * a handful of rows far longer than the rest) */
+    m->lanes_mostly_pad = rc == 0 && th.n_pad * 8 > m->nnz;
+    if (auto_choice && m->lanes_mostly_pad) {
+        spmv_lanes_free(&th);
+        rc = -2;
+    }
+    m->lanes_rc = rc;
+    if (rc == -1) {
+        spmv_set_error("out of host memory for the LANES conversion");
+        return -1;
+    }
+    if (rc == -2) {
+        spmv_set_error("matrix not representable in the LANES layout or not suited to it");
+        return -2;
+    }
+    const size_t nw = (size_t)th.n_waves;
+    const size_t n_alloc = (size_t)th.n_packed + SPMV_TILE_PAD;
+    const size_t sr = (size_t)th.S * (size_t)m->rows;
+    const size_t pbytes = ((size_t)th.n_slots + 64) * (size_t)m->elem;
+    void *d_w = nullptr, *d_s = nullptr, *d_i = nullptr, *d_c = nullptr, *d_v = nullptr, *d_p = nullptr;
+    hipError_t e = hipMalloc(&d_w, (nw + 1) * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_s, (nw + 1) * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_i, (sr + 1) * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_c, n_alloc * sizeof(uint16_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_v, n_alloc * (size_t)m->elem);
+    if (e == hipSuccess)
+        e = hipMalloc(&d_p, pbytes);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_w, th.wptr, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_s, th.wslot, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_i, th.islot, sr * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemset(d_p, 0, pbytes);
+    if (e != hipSuccess) {
+        spmv_set_error("LANES upload failed: %s", hipGetErrorString(e));
+        (void)hipFree(d_w), (void)hipFree(d_s), (void)hipFree(d_i), (void)hipFree(d_c), (void)hipFree(d_v);
+        (void)hipFree(d_p);
+        spmv_lanes_free(&th);
+        return -1;
+    }
+    m->dl.wptr = (const int32_t *)d_w;
+    m->dl.wslot = (const int32_t *)d_s;
+    m->dl.islot = (const int32_t *)d_i;
+    m->dl.col = (const uint16_t *)d_c;
+    m->dl.val = d_v;
+    m->dl.partial = d_p;
+    m->dl.elem = m->elem;
+    m->dl.W = th.W;
+    m->dl.S = th.S;
+    m->dl.WPB = th.WPB;
+    m->dl.B = th.B;
+    m->dl.xbytes = g_stripe_xbytes;
+    m->dl.rows = m->rows;
+    m->dl.cols = m->cols;
+    m->device_bytes += (nw + 1) * 8 + sr * 4 + n_alloc * (2 + (size_t)m->elem) + pbytes;
+    m->have_lanes = true;
+    spmv_lanes_free(&th);
+    return 0;
+}
+
 spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const int *colidx, int rows,
                                         int elem_size, int device, int row_begin, int row_end,
                                         int cols_hint)
@@ -726,6 +851,12 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
         m->plan = plan;
         m->param = m->ds.W;
         break;
+    case SPMV_HIP_PLAN_LANES:
+        if (ensure_lanes(m, nullptr, nullptr, 0, false))
+            return -1;
+        m->plan = plan;
+        m->param = m->dl.W;
+        break;
     case SPMV_HIP_PLAN_ORDERED:
         m->plan = plan;
         m->param = 1;
@@ -760,6 +891,7 @@ static int n_launches(const spmv_hip_matrix *m)
     int longk = m->sp.nseg > 0 ? 1 + (m->sp.nlrow > 0) : 0;
     switch (m->plan) {
     case SPMV_HIP_PLAN_STRIPED: return 2;
+    case SPMV_HIP_PLAN_LANES: return 2;
     case SPMV_HIP_PLAN_STREAM: return 1 + longk;
     case SPMV_HIP_PLAN_BINNED: {
         int n = longk;
@@ -788,6 +920,7 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     out->mean_row_len = m->st.mean_len;
     out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED     ? m->dt.B
                     : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.S * m->ds.B
+                    : m->plan == SPMV_HIP_PLAN_LANES   ? m->dl.S * m->dl.B
                                                        : m->sp.nblk;
     out->n_long_rows = m->sp.n_long_rows;
     out->n_launches = n_launches(m);
@@ -806,11 +939,13 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
 int spmvd_spmv_dot(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream, const void *v_dev,
                    void *dot_part)
 {
-    if (!m || m->rows == 0 || m->plan != SPMV_HIP_PLAN_STRIPED || (reinterpret_cast<uintptr_t>(x_dev) & 15u) != 0)
+    if (!m || m->rows == 0 || (m->plan != SPMV_HIP_PLAN_STRIPED && m->plan != SPMV_HIP_PLAN_LANES) ||
+        (reinterpret_cast<uintptr_t>(x_dev) & 15u) != 0)
         return 0;
     HIPCHK(hipSetDevice(m->device), return -1);
     hipStream_t st = stream_of(m->device, stream);
-    int rc = spmvk_striped(&m->ds, x_dev, y_dev, st, v_dev, dot_part);
+    int rc = m->plan == SPMV_HIP_PLAN_LANES ? spmvk_lanes(&m->dl, x_dev, y_dev, st, v_dev, dot_part)
+                                            : spmvk_striped(&m->ds, x_dev, y_dev, st, v_dev, dot_part);
     if (rc) {
         spmv_set_error("kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return -1;
@@ -837,10 +972,12 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
     switch (m->plan) {
     case SPMV_HIP_PLAN_ORDERED: rc = spmvk_ordered(&d, x_dev, y_dev, st); break;
     case SPMV_HIP_PLAN_STRIPED:
+    case SPMV_HIP_PLAN_LANES:
     case SPMV_HIP_PLAN_TILED:
         if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0) {
-            rc = m->plan == SPMV_HIP_PLAN_TILED ? spmvk_tiled(&m->dt, x_dev, y_dev, st)
-                                                : spmvk_striped(&m->ds, x_dev, y_dev, st, nullptr, nullptr);
+            rc = m->plan == SPMV_HIP_PLAN_TILED     ? spmvk_tiled(&m->dt, x_dev, y_dev, st)
+                 : m->plan == SPMV_HIP_PLAN_LANES   ? spmvk_lanes(&m->dl, x_dev, y_dev, st, nullptr, nullptr)
+                                                    : spmvk_striped(&m->ds, x_dev, y_dev, st, nullptr, nullptr);
             break;
         }
         /* k_tiled stages x with 16-byte loads; a misaligned x goes to the row-segment kernel */

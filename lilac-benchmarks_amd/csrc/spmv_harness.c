@@ -42,7 +42,7 @@
  *                      matrix should call spmv_hip_release() first (or use compare/pointer/off),
  *                      because recycled heap pages would still be read-only for system calls.
  *                      compare: no page protection, every call compares the arrays byte for byte.
- *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped
+ *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped | lanes
  *   SPMV_HIP_DEVICES = number of GPUs to row-partition over (default 1; "all")
  *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
  *                      than devices wraps around -- lets the multi-GPU code path
@@ -402,8 +402,14 @@ static void lazy_init(void)
             G.plan_param = v[6] == ':' ? atoi(v + 7) : 64;
         } else if (!strcmp(v, "binned"))
             G.plan = SPMV_HIP_PLAN_BINNED;
+        else if (!strcmp(v, "tiled"))
+            G.plan = SPMV_HIP_PLAN_TILED;
+        else if (!strcmp(v, "striped"))
+            G.plan = SPMV_HIP_PLAN_STRIPED;
+        else if (!strcmp(v, "lanes"))
+            G.plan = SPMV_HIP_PLAN_LANES;
         else if (strcmp(v, "auto"))
-            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped", v);
+            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped|lanes", v);
     }
     G.stats = env_int("SPMV_HIP_STATS", 0);
     G.verbose = env_int("SPMV_HIP_VERBOSE", 0);

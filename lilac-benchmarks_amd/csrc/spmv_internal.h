@@ -143,6 +143,22 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
                        int elem_size, int xbytes, int wpb, int target_wgs, int epl, spmv_striped_host *t);
 void spmv_striped_free(spmv_striped_host *t);
 
+/* LANES plan (spmv_lanes.c): the STRIPED decomposition with whole (row, stripe) segments dealt to
+ * lanes; geometry (W, S, B, WPB) as spmv_striped_geometry with 4 entries per lane per sub-window. */
+#define SPMV_LANES_QUEUE 4 /* finished sums a lane can hold before its wave writes them out */
+typedef struct spmv_lanes_host {
+    int elem, W, S, WPB, B, n_waves;
+    int64_t n_packed, n_pad, n_slots;
+    void *val;
+    uint16_t *col;
+    int32_t *wptr;  /* [n_waves + 1] first entry of each wave's run (multiples of 256)     */
+    int32_t *wslot; /* [n_waves + 1] first partial-sum slot of each wave                    */
+    int32_t *islot; /* [S * rows]    slot of (stripe, row), -1 = no entry in that stripe    */
+} spmv_lanes_host;
+int spmv_lanes_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,
+                     int elem_size, int xbytes, int wpb, int target_wgs, spmv_lanes_host *t);
+void spmv_lanes_free(spmv_lanes_host *t);
+
 /* Adaptive choice (SPMV_HIP_PLAN_AUTO): fills *plan / *param from the row statistics. */
 void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *plan, int *param);
 
@@ -180,6 +196,16 @@ typedef struct spmv_dev_striped {
     int elem, W, S, WPB, B, EPL, rows, cols;
     int xbytes; /* LDS stripe capacity (65536 / 131072) the layout was built for */
 } spmv_dev_striped;
+typedef struct spmv_dev_lanes {
+    const int32_t *wptr, *wslot, *islot;
+    const uint16_t *col;
+    const void *val;
+    void *partial; /* T[n_slots] */
+    int elem, W, S, WPB, B, rows, cols;
+    int xbytes;
+} spmv_dev_lanes;
+/* dotv as in spmvk_striped */
+int spmvk_lanes(const spmv_dev_lanes *t, const void *x, void *y, void *stream, const void *dotv, void *dot_part);
 struct spmv_hip_matrix;
 /* y = A x plus block partials of y . v when the plan can fold them in (STRIPED): returns the number
  * of partials (one per 256 rows), 0 = not folded (run a separate dot), -1 = error */

@@ -853,6 +853,182 @@ __global__ void __launch_bounds__(SPMV_WG) k_stripe_sum(const T *__restrict__ pa
     }
 }
 
+/* ================================ k_lanes ======================================= */
+/*
+ * LANES plan (layout: spmv_lanes.c).  Workgroup = (stripe s, row range b) as in k_striped: stage
+ * the stripe of x into LDS once, one barrier, then every wave streams its run of packed entries
+ * through a static ring of register sets.  The difference is what a lane does with its four
+ * entries of a sub-window: they are consecutive entries of the lane's OWN stream of whole
+ * (row, stripe) segments, so it just multiplies and adds; at a flagged entry the sum of the lane's
+ * k-th segment is finished and belongs into slot wslot + 64 k + lane.  It waits in the lane's own
+ * 4-deep LDS queue until every lane of the wave is past its k-th segment, then the wave writes the 64
+ * sums of group k with one coalesced store (scattered 8-byte stores, one per segment, cost 15 us on
+ * class C).  A lane that is 4 or more groups ahead of the write-out stores directly and sets bit k
+ * of a mask so that the group's write-out leaves its slot alone (the layout guarantees < 32 ahead).
+ * About 50 vector instructions per 256 entries instead of 150, no cross-lane data traffic.
+ */
+template <typename T, int WPB, int R, int XT_BYTES>
+__global__ void __launch_bounds__(WPB * 64, 4) k_lanes(const int *__restrict__ wptr, const int *__restrict__ wslot,
+                                                       const unsigned short *__restrict__ pcol,
+                                                       const T *__restrict__ pval, const T *__restrict__ x,
+                                                       T *__restrict__ partial, int cols, int B, int wcols)
+{
+    using VT = typename Vec16<T>::val_t;
+    constexpr int E = Vec16<T>::E;
+    constexpr int EPL = 4;
+    constexpr int W = XT_BYTES / (int)sizeof(T);
+    constexpr int SUB = 64 * EPL;
+    constexpr int NT = WPB * 64;
+    constexpr int XV = W / (NT * E);
+    constexpr int Q = SPMV_LANES_QUEUE;
+    static_assert(XV * NT * E == W, "stripe must be a whole number of 16-byte loads per thread");
+    static_assert((R + 1) * SUB <= SPMV_TILE_PAD, "look-ahead must stay inside the padding");
+    static_assert((Q & (Q - 1)) == 0, "queue depth must be a power of two");
+    __shared__ __attribute__((aligned(16))) T s_x[W];
+    __shared__ __attribute__((aligned(16))) T s_q[WPB][Q][64];
+
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int s = blockIdx.x / B; /* stripe */
+    const int wi = blockIdx.x * WPB + w;
+    const int P0 = __builtin_amdgcn_readfirstlane(wptr[wi]);
+    const int P1 = __builtin_amdgcn_readfirstlane(wptr[wi + 1]); /* P1 - P0 is a multiple of SUB */
+    const unsigned int slot0 = (unsigned int)__builtin_amdgcn_readfirstlane(wslot[wi]);
+    const unsigned int ngroups = ((unsigned int)__builtin_amdgcn_readfirstlane(wslot[wi + 1]) - slot0) >> 6;
+
+    StripeRegs<T, EPL> set[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        stripe_load<T, EPL>(set[r], pval, pcol, P0 + r * SUB, lane);
+
+    {
+        const int c0 = s * wcols;
+        const int nx = (cols - c0) < wcols ? (cols - c0) : wcols;
+        const T *xs = x + c0;
+        VT xr[XV];
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int i = (k * NT + tid) * E;
+            const T *src = (i + E <= nx) ? xs + i : x; /* no branch around a load; see k_tiled */
+            xr[k] = *reinterpret_cast<const VT *>(src);
+        }
+#pragma unroll
+        for (int k = 0; k < XV; ++k)
+            *reinterpret_cast<VT *>(&s_x[(k * NT + tid) * E]) = xr[k];
+        const int tail = nx % E;
+        if (tail != 0 && (((nx - tail) / E) % NT) == tid)
+            for (int j = 0; j < tail; ++j)
+                s_x[nx - tail + j] = xs[nx - tail + j];
+    }
+    wg_barrier_lds();
+
+    T *__restrict__ out = partial + slot0;
+    T acc = (T)0;
+    unsigned int kseg = 0;     /* segments this lane has finished                                  */
+    unsigned int direct = 0;   /* bit (k & 31): segment k went straight to memory                  */
+    unsigned int gflushed = 0; /* wave-uniform: groups already written out                         */
+    auto write_out = [&]() __attribute__((always_inline)) { /* group gflushed leaves the queues */
+        const T v = s_q[w][gflushed & (Q - 1)][lane];
+        if (!((direct >> (gflushed & 31u)) & 1u))
+            store_untracked(out + (gflushed * 64u + (unsigned int)lane), v);
+        direct &= ~(1u << (gflushed & 31u));
+        ++gflushed;
+    };
+    auto sub_window = [&](StripeRegs<T, EPL> &regs, const int sb, const bool reload)
+                          __attribute__((always_inline)) {
+        T v[EPL], xv[EPL];
+        unsigned int c[EPL];
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            c[k] = regs.col(k);
+            v[k] = regs.val(k);
+            xv[k] = s_x[c[k] & (W - 1)];
+        }
+        if (reload) /* compile-time at every call site */
+            stripe_load<T, EPL>(regs, pval, pcol, sb + R * SUB, lane);
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            acc = fmadd(v[k], xv[k], acc);
+            if (c[k] >> 15) { /* last entry of the lane's segment number kseg */
+                if (kseg - gflushed < (unsigned int)Q) {
+                    s_q[w][kseg & (Q - 1)][lane] = acc;
+                } else {
+                    store_untracked(out + (kseg * 64u + (unsigned int)lane), acc);
+                    direct |= 1u << (kseg & 31u);
+                }
+                ++kseg;
+                acc = (T)0;
+            }
+        }
+        /* every lane past group gflushed?  (the wave's last group may be short of lanes: it leaves
+         * after the loop) */
+        while (gflushed + 1 < ngroups && __builtin_amdgcn_ballot_w64(kseg > gflushed) == ~0ull)
+            write_out();
+    };
+    const int nsub = (P1 - P0) / SUB;
+    int j = 0;
+    for (; j + R <= nsub; j += R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            sub_window(set[r], P0 + (j + r) * SUB, true);
+    }
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r)
+        if (j + r < nsub) /* wave-uniform */
+            sub_window(set[r], P0 + (j + r) * SUB, false);
+    /* what is still queued: lanes without a segment in a group write nothing */
+    while (gflushed < ngroups) {
+        const T v = s_q[w][gflushed & (Q - 1)][lane];
+        if (kseg > gflushed && !((direct >> (gflushed & 31u)) & 1u))
+            store_untracked(out + (gflushed * 64u + (unsigned int)lane), v);
+        ++gflushed;
+    }
+}
+
+/* y[r] = the row's slots added in stripe order (islot < 0: nothing in that stripe); dotv as in
+ * k_stripe_sum */
+template <typename T>
+__global__ void __launch_bounds__(SPMV_WG) k_lane_sum(const T *__restrict__ partial, const int *__restrict__ islot,
+                                                      T *__restrict__ y, int rows, int S,
+                                                      const T *__restrict__ dotv, T *__restrict__ dot_part)
+{
+    const int r = blockIdx.x * SPMV_WG + threadIdx.x;
+    T acc = (T)0;
+    if (r < rows) {
+        const int *ip = islot + r;
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {
+            int q[8];
+            T v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                q[k] = ip[(size_t)(s + k) * rows];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v[k] = partial[q[k] < 0 ? 0 : q[k]];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                acc = acc + (q[k] < 0 ? (T)0 : v[k]);
+        }
+        for (; s < S; ++s) {
+            const int q = ip[(size_t)s * rows];
+            const T v = partial[q < 0 ? 0 : q];
+            acc = acc + (q < 0 ? (T)0 : v);
+        }
+        y[r] = acc;
+    }
+    if (dotv) { /* kernel-uniform */
+        __shared__ T s_w[SPMV_WG / 64];
+        T d = r < rows ? acc * dotv[r] : (T)0;
+        for (int o = 32; o; o >>= 1)
+            d += __shfl_xor(d, o, 64);
+        if ((threadIdx.x & 63) == 0)
+            s_w[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            dot_part[blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+    }
+}
+
 /* ================================ k_long ======================================== */
 template <typename T>
 __global__ void __launch_bounds__(SPMV_WG) k_long(const int *__restrict__ seg,
@@ -1189,6 +1365,55 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
     else
         hipLaunchKernelGGL(k_stripe_sum<float>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
                            (const float *)t->partial, (float *)y, t->rows, t->S, (const float *)dotv,
+                           (float *)dot_part);
+    return launch_status();
+}
+
+int spmvk_lanes(const spmv_dev_lanes *t, const void *x, void *y, void *stream, const void *dotv, void *dot_part)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (t->rows <= 0)
+        return 0;
+    const int grid = t->S * t->B;
+#define SPMV_LL(T, WPB, R, XT)                                                                          \
+    hipLaunchKernelGGL((k_lanes<T, WPB, R, XT>), dim3(grid), dim3(WPB * 64), 0, st, t->wptr, t->wslot,   \
+                       t->col, (const T *)t->val, (const T *)x, (T *)t->partial, t->cols, t->B, t->W)
+#define SPMV_LLR(T, WPB, XT)                                                                            \
+    do {                                                                                                \
+        if (g_tune_tile_k == 4)                                                                         \
+            SPMV_LL(T, WPB, 4, XT);                                                                     \
+        else if (g_tune_tile_k == 3)                                                                    \
+            SPMV_LL(T, WPB, 3, XT);                                                                     \
+        else                                                                                            \
+            SPMV_LL(T, WPB, 2, XT);                                                                     \
+    } while (0)
+    if (t->WPB == 16 && t->xbytes == 131072) {
+        if (t->elem == 8)
+            SPMV_LLR(double, 16, 131072);
+        else
+            SPMV_LLR(float, 16, 131072);
+    } else if (t->WPB == 16 && t->xbytes == 65536) {
+        if (t->elem == 8)
+            SPMV_LLR(double, 16, 65536);
+        else
+            SPMV_LLR(float, 16, 65536);
+    } else if (t->WPB == 8 && t->xbytes == 65536) {
+        if (t->elem == 8)
+            SPMV_LLR(double, 8, 65536);
+        else
+            SPMV_LLR(float, 8, 65536);
+    } else {
+        return (int)hipErrorInvalidValue;
+    }
+#undef SPMV_LLR
+#undef SPMV_LL
+    if (t->elem == 8)
+        hipLaunchKernelGGL(k_lane_sum<double>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
+                           (const double *)t->partial, t->islot, (double *)y, t->rows, t->S, (const double *)dotv,
+                           (double *)dot_part);
+    else
+        hipLaunchKernelGGL(k_lane_sum<float>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
+                           (const float *)t->partial, t->islot, (float *)y, t->rows, t->S, (const float *)dotv,
                            (float *)dot_part);
     return launch_status();
 }

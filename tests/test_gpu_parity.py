@@ -61,7 +61,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
             try:
                 m.set_plan(plan, param)
             except RuntimeError as e:
-                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED) and "not representable" in str(e):
+                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED, pkg.PLAN_LANES) and "not representable" in str(e):
                     continue  # a chunk above 65535 entries: AUTO falls back to STREAM for such matrices
                 raise
             y = m.spmv_host(x)
@@ -75,7 +75,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
 
 
 def all_plans(pkg):
-    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0)]
+    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0), (pkg.PLAN_LANES, 0)]
     P += [(pkg.PLAN_VECTOR, l) for l in (1, 2, 4, 8, 16, 32, 64)]
     return P
 
@@ -377,7 +377,8 @@ def test_class_c_full_size(pkg, backend, oracle):
         assert inf["algorithmic_bytes"] == 436452700
         results = {}
         for plan, param in [(pkg.PLAN_AUTO, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_VECTOR, 64), (pkg.PLAN_VECTOR, 32),
-                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0)]:
+                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0),
+                            (pkg.PLAN_LANES, 0)]:
             dm.set_plan(plan, param)
             y = dm.spmv_host(x)
             results[(plan, param)] = y

@@ -351,3 +351,144 @@ def test_striped_layout_does_not_depend_on_the_thread_count():
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.strip())
     assert outs[0] == outs[1] == outs[2] and len(outs[0].split()[0]) == 64
+
+
+# ------------------------------------------------------------------ LANES layout (csrc/spmv_lanes.c)
+class LanesHost(ctypes.Structure):
+    _fields_ = [("elem", ctypes.c_int), ("W", ctypes.c_int), ("S", ctypes.c_int), ("WPB", ctypes.c_int),
+                ("B", ctypes.c_int), ("n_waves", ctypes.c_int), ("n_packed", ctypes.c_int64),
+                ("n_pad", ctypes.c_int64), ("n_slots", ctypes.c_int64), ("val", ctypes.c_void_p),
+                ("col", ctypes.POINTER(ctypes.c_uint16)), ("wptr", ctypes.POINTER(ctypes.c_int32)),
+                ("wslot", ctypes.POINTER(ctypes.c_int32)), ("islot", ctypes.POINTER(ctypes.c_int32))]
+
+
+def lanes_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6):
+    """Runs csrc/spmv_lanes.c, checks the invariants k_lanes relies on and walks the layout exactly like
+    the kernel: every lane on its own, slot numbers from the boustrophedon sequence, no row numbers."""
+    rows = rs.size - 1
+    cols = int(ci.max()) if ci.size else 0
+    t = LanesHost()
+    lib.spmv_lanes_build.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 7 + [ctypes.POINTER(LanesHost)]
+    rc = lib.spmv_lanes_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, rows, cols, a.dtype.itemsize,
+                              xbytes, wpb, wgs, ctypes.byref(t))
+    if rc != 0:
+        return rc, None
+    nw = t.n_waves
+    assert nw == t.S * t.B * t.WPB
+    wptr = np.ctypeslib.as_array(t.wptr, (nw + 1,)).astype(np.int64)
+    wslot = np.ctypeslib.as_array(t.wslot, (nw + 1,)).astype(np.int64)
+    islot = np.ctypeslib.as_array(t.islot, (t.S * rows,)).astype(np.int64).reshape(t.S, rows)
+    col = np.ctypeslib.as_array(t.col, (t.n_packed + 1,)).astype(np.int64)[:t.n_packed]
+    ctype = ctypes.c_double if a.dtype == np.float64 else ctypes.c_float
+    val = np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctype)), (t.n_packed + 1,))[:t.n_packed]
+    assert np.all(wptr % 256 == 0) and np.all(np.diff(wptr) >= 0) and wptr[-1] == t.n_packed
+    assert wslot[-1] == t.n_slots and np.all(np.diff(wslot) >= 0)
+    G = 16 // a.dtype.itemsize
+    # every non-empty (stripe, row) pair owns exactly one slot, and one flagged entry exists per slot
+    rowid = np.repeat(np.arange(rows), np.diff(rs))
+    cnt = np.zeros((t.S, rows), np.int64)
+    np.add.at(cnt, ((ci.astype(np.int64) - 1) // t.W, rowid), 1)
+    assert np.array_equal(islot >= 0, cnt > 0)
+    used = np.sort(islot[islot >= 0])
+    assert used.size == np.unique(used).size and (used.size == 0 or used[-1] < t.n_slots)
+    assert int((col >> 15).sum()) == used.size
+    assert t.n_pad == t.n_packed - ci.size
+    partial = np.full(t.n_slots + 1, np.nan, a.dtype)
+    per = t.B * t.WPB
+    xs = np.zeros(t.S * t.W + 1, a.dtype)
+    xs[:x.size] = x
+    QUEUE = 4
+    n_direct = 0
+    for wi in range(nw):
+        s = wi // per
+        p0, p1 = int(wptr[wi]), int(wptr[wi + 1])
+        nq = (p1 - p0) // 256
+        s0, s1 = int(wslot[wi]), int(wslot[wi + 1])
+        assert (s1 - s0) % 64 == 0
+        if nq == 0:
+            assert s0 == s1
+            continue
+        ngroups = (s1 - s0) // 64
+        c = col[p0:p1].reshape(nq, 64, 4)  # [sub-window][lane][entry of the lane]
+        v = val[p0:p1].reshape(nq, 4 // G, 64, G).transpose(0, 2, 1, 3).reshape(nq, 64, 4)  # undo the 16-byte interleave
+        # the kernel in lockstep: per-lane queue of QUEUE finished sums, groups leave in order as soon as every
+        # lane is past them; a lane QUEUE or more groups ahead stores directly and masks its slot of that group
+        acc = np.zeros(64, a.dtype)
+        kseg = np.zeros(64, np.int64)
+        queue = np.full((QUEUE, 64), np.nan, a.dtype)
+        direct = np.zeros((32, 64), bool)
+        gflushed = 0
+        written = np.zeros(s1 - s0, np.int64)
+
+        def write_out(g, only=None):
+            sel = ~direct[g % 32] if only is None else (only & ~direct[g % 32])
+            idx = s0 + 64 * g + np.nonzero(sel)[0]
+            partial[idx] = queue[g % QUEUE][sel]
+            written[idx - s0] += 1
+            direct[g % 32] = False
+
+        for q in range(nq):
+            for i in range(4):
+                cc = c[q, :, i]
+                acc = acc + v[q, :, i] * xs[s * t.W + (cc & 0x7fff)]
+                for lane in np.nonzero((cc >> 15) != 0)[0]:
+                    k = int(kseg[lane])
+                    assert k < ngroups and k - gflushed < 32
+                    if k - gflushed < QUEUE:
+                        queue[k % QUEUE, lane] = acc[lane]
+                    else:
+                        partial[s0 + 64 * k + lane] = acc[lane]
+                        written[64 * k + lane] += 1
+                        assert not direct[k % 32, lane]
+                        direct[k % 32, lane] = True
+                        n_direct += 1
+                    kseg[lane] += 1
+                    acc[lane] = 0
+            while gflushed + 1 < ngroups and np.all(kseg > gflushed):  # once per sub-window
+                write_out(gflushed)
+                gflushed += 1
+        while gflushed < ngroups:
+            write_out(gflushed, only=kseg > gflushed)
+            gflushed += 1
+        assert not direct.any() and written.max() <= 1
+        assert written.sum() == int(kseg.sum())  # every finished segment reached memory exactly once
+    assert not np.isnan(partial[islot[islot >= 0]]).any()
+    y = np.zeros(rows, a.dtype)
+    for s in range(t.S):
+        y = y + np.where(islot[s] >= 0, partial[np.maximum(islot[s], 0)], a.dtype.type(0))
+    geo = dict(W=t.W, S=t.S, B=t.B, WPB=t.WPB, n_packed=t.n_packed, n_pad=t.n_pad, n_slots=t.n_slots, n_direct=n_direct)
+    lib.spmv_lanes_free.argtypes = [ctypes.POINTER(LanesHost)]
+    lib.spmv_lanes_free(ctypes.byref(t))
+    return 0, (y, geo)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lanes_layout(lib, oracle, dtype):
+    rng = np.random.default_rng(6)
+    eps = 2.0 ** -53 if dtype == np.float64 else 2.0 ** -24
+    cases = [matgen.random_csr(18, 900, 30000, 40, dtype, empty_frac=0.05, sort_cols=False, distinct=False),
+             matgen.npb_like(19, 700, 120, dtype),
+             matgen.random_csr(20, 50, 20000, 300, dtype),
+             matgen.random_csr(21, 3000, 9000, 6, dtype, empty_frac=0.3),  # many empty (row, stripe) pairs: no fillers
+             matgen.csr_from_lengths(rng, [30] + [1] * 5000 + [25] + [2] * 700, 8000, dtype)]  # one lane held up while the others run through 1-entry segments
+    hit_direct = False
+    for rs, ci, a in cases:
+        rows = rs.size - 1
+        x = rng.standard_normal(int(ci.max())).astype(dtype)
+        rc, res = lanes_emulate(lib, rs, ci, a, x, wgs=1 if rs.size > 5000 else 6)  # few, long waves for the last case
+        assert rc == 0
+        y, geo = res
+        assert geo["S"] == -(-int(ci.max()) // geo["W"]) and geo["S"] * geo["B"] <= 6
+        hit_direct = hit_direct or geo["n_direct"] > 0
+        y_ref = oracle.spmv(a, x, rs, ci, rows)
+        tol = (np.diff(rs) + geo["S"] + 2) * eps * oracle.absum(a, x, rs, ci, rows)
+        assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol)
+    assert hit_direct  # the overflow path of the queue was exercised
+
+
+def test_lanes_rejects_one_huge_row(lib):
+    """A row that is most of the matrix would leave 63 lanes of its wave padding: not worth it."""
+    rng = np.random.default_rng(7)
+    rs, ci, a = matgen.csr_from_lengths(rng, [29000] * 8 + [3] * 30000, 30000, np.float64)
+    rc, _ = lanes_emulate(lib, rs, ci, a, np.ones(30000), wgs=1)
+    assert rc == -2

@@ -97,6 +97,32 @@ template <int D, int SHAPE> __global__ void __launch_bounds__(512, 4) k_tileshap
     if (acc == 12345.678 && ca == 77) *sink = 1;
 }
 
+// One interleaved stream instead of two arrays: per step a wave reads ONE contiguous 2560-byte record
+// = [256 x u16 columns][256 x f64 values]; lane l takes 8 B of columns and two 16-byte value units.
+template <int D> __global__ void __launch_bounds__(512, 4) k_recshape(const char* __restrict__ rec, size_t steps, float* sink) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t g = (size_t)blockIdx.x * 8 + w;
+    d2 va[D], vb[D]; u2 cc[D];
+    auto load = [&](int d, size_t t) {
+        const char* base = rec + (g * steps + t) * 2560;
+        cc[d] = *(const u2*)(base + 8 * lane);
+        va[d] = *(const d2*)(base + 512 + 16 * lane);
+        vb[d] = *(const d2*)(base + 512 + 1024 + 16 * lane);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(d, d);
+    double acc = 0; unsigned int ca = 0;
+    for (size_t t = 0; t + D <= steps; t += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            acc += va[d][0] + va[d][1] + vb[d][0] + vb[d][1]; ca += cc[d][0] ^ cc[d][1];
+            size_t nt = t + d + D;
+            load(d, nt < steps ? nt : d);
+        }
+    }
+    if (acc == 12345.678 && ca == 77) *sink = 1;
+}
+
 template <typename F> float time_ms(F f, int reps) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     f(); CHECK(hipDeviceSynchronize());
@@ -132,6 +158,9 @@ int main(int argc, char** argv) {
         size_t b3 = entries * 10;
 #define TS(D, SH) rep("tileshape D=" #D " shape=" #SH, time_ms([&] { k_tileshape<D, SH><<<blocks, 512>>>(val, col, steps, sink); }, 20), b3);
         TS(2, 0) TS(4, 0) TS(6, 0) TS(2, 1) TS(4, 1) TS(6, 1) TS(2, 2) TS(4, 2) TS(6, 2)
+        char* rec; CHECK(hipMalloc(&rec, entries * 10 + 65536)); CHECK(hipMemset(rec, 0, entries * 10));
+#define RS(D) rep("recshape  D=" #D " (one interleaved stream)", time_ms([&] { k_recshape<D><<<blocks, 512>>>(rec, steps, sink); }, 20), b3);
+        RS(2) RS(4) RS(6)
     }
     return 0;
 }
