@@ -694,6 +694,8 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__
         if (tail != 0 && (((nx - tail) / E) % NT) == tid)
             for (int j = 0; j < tail; ++j)
                 s_x[nx - tail + j] = xs[nx - tail + j];
+        if (tid == NT - 1) /* the thread that wrote the buffer's last 16 bytes: fillers multiply with 0 */
+            s_x[W - 1] = (T)0;
     }
     wg_barrier_lds();
 

@@ -313,7 +313,7 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
         *param = 64;
         return;
     }
-    const int W = SPMV_STRIPE_XBYTES / elem_size;
+    const int W = SPMV_STRIPE_XBYTES / elem_size - 16 / elem_size; /* spmv_striped_geometry */
     const int S = cols > 0 ? (cols + W - 1) / W : 1;
     if (st->rows >= 32768 && cols >= W / 2 && S <= 128 && st->mean_len / (double)S >= 4.0) {
         *plan = SPMV_HIP_PLAN_STRIPED;

@@ -56,6 +56,10 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, int xbytes, int wp
     int wmax = xbytes / elem_size; /* columns that fit the LDS stripe buffer */
     if (wmax > 32768)
         wmax = 32768; /* 15 column bits */
+    /* the top 16 bytes of the buffer are not x: its last element is kept at 0 and is what the filler
+     * of an empty (row, stripe) segment multiplies with, so that a non-finite x entry cannot reach a
+     * row that does not reference it (0 * Inf = NaN) */
+    wmax -= 16 / elem_size;
     if (target_wgs < 1)
         target_wgs = 1;
     /*
@@ -186,7 +190,8 @@ static void pass_scatter(int64_t lo, int64_t hi, void *vc)
     free(fill);
 }
 
-/* pass 4, over stripes: the filler of an empty segment is a flag-only entry (value 0, column 0) */
+/* pass 4, over stripes: the filler of an empty segment is a flag-only entry: value 0, and as its
+ * column the last element of the LDS buffer, which the kernel keeps at 0 (spmv_striped_geometry) */
 static void pass_fillers(int64_t lo, int64_t hi, void *vc)
 {
     build_ctx *c = (build_ctx *)vc;
@@ -197,7 +202,7 @@ static void pass_fillers(int64_t lo, int64_t hi, void *vc)
         const int32_t *st = c->start + (size_t)s * c->rows;
         for (int r = 0; r < c->rows; ++r)
             if (cs[r] == 0)
-                c->t->col[c->sbase[s] + st[r]] = 0x8000u;
+                c->t->col[c->sbase[s] + st[r]] = (uint16_t)(0x8000u | (unsigned)(c->W + 16 / c->elem - 1));
     }
 }
 

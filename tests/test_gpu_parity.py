@@ -560,3 +560,35 @@ def test_malformed_matrices_are_refused_before_any_kernel_runs(backend):
                 os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == -6 and "column index 0 < 1" in r.stderr  # SIGABRT with the diagnostic
+
+
+def test_non_finite_x_entries_stay_in_the_rows_that_reference_them(pkg, backend, oracle):
+    """Re-laid-out plans hold zero-valued filler entries; 0 * Inf is NaN, so a filler must never meet x.
+    Inf / NaN at the first column of every stripe (what STRIPED's fillers used to multiply with) and
+    elsewhere: rows that do not reference those columns must come out as if x were finite there."""
+    rs, ci, a = matgen.random_csr(41, 3000, 40000, 12)
+    rows = 3000
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal(40000)
+    bad_cols = np.array([0, 16382, 16384, 32764, 32768, 12345, 39999])
+    x[bad_cols] = [np.inf, -np.inf, np.inf, np.nan, np.inf, np.nan, -np.inf]
+    touched = np.zeros(rows, bool)
+    rowid = np.repeat(np.arange(rows), np.diff(rs))
+    touched[rowid[np.isin(ci - 1, bad_cols)]] = True
+    assert touched.any() and not touched.all()
+    xf = x.copy()
+    xf[bad_cols] = 0.0
+    y_ref = oracle.spmv(a, x, rs, ci, rows)
+    assert np.all(np.isfinite(y_ref[~touched])) and not np.isfinite(y_ref[touched]).any()
+    absum = oracle.absum(a, xf, rs, ci, rows)
+    m = backend.matrix(a, rs, ci, rows)
+    try:
+        for plan, param in all_plans(pkg):
+            m.set_plan(plan, param)
+            y = m.spmv_host(x)
+            tag = "plan %s/%d" % (pkg.abi.PLAN_NAMES[plan], param)
+            assert not np.isfinite(y[touched]).any(), tag
+            assert np.all(np.isfinite(y[~touched])), tag
+            assert_close_rows(y[~touched], y_ref[~touched], absum[~touched], np.diff(rs)[~touched], np.float64, tag)
+    finally:
+        m.close()

@@ -273,7 +273,16 @@ def striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6, epl=4):
         run = a.dtype.type(0)
         for q in range(int(wptr[wi]), int(wptr[wi + 1])):
             c = int(col[q])
-            run = run + val[q] * x[s * t.W + (c & 0x7fff)] if (c & 0x7fff) + s * t.W < x.size or val[q] != 0 else run
+            lc = c & 0x7fff
+            if lc >= t.W:  # a filler: it multiplies with the zeroed last element of the LDS buffer, never with x
+                assert lc == t.W + 16 // a.dtype.itemsize - 1 and val[q] == 0 and c >> 15
+                xv = a.dtype.type(0)
+            elif s * t.W + lc < x.size:
+                xv = x[s * t.W + lc]
+            else:  # padding of the wave's run (value 0, column 0 of a stripe that ends early)
+                assert val[q] == 0
+                xv = a.dtype.type(0)
+            run = run + val[q] * xv
             if c >> 15:
                 partial[s, row] = run
                 row += 1
@@ -305,7 +314,7 @@ def test_striped_layout(lib, oracle, dtype):
         rc4, res4 = striped_emulate(lib, rs, ci, a, x, epl=8)
         assert rc4 == 0 and np.array_equal(res4[0], y)  # same sums whatever the sub-window size
         assert geo["S"] == -(-int(ci.max()) // geo["W"]) and geo["W"] * a.dtype.itemsize <= 65536
-        assert geo["S"] * geo["B"] <= 6 and geo["W"] % 128 == 0
+        assert geo["S"] * geo["B"] <= 6 and (geo["W"] + 16 // a.dtype.itemsize) * a.dtype.itemsize == 65536
         y_ref = oracle.spmv(a, x, rs, ci, rows)
         tol = (np.diff(rs) + geo["S"] + 2) * eps * oracle.absum(a, x, rs, ci, rows)
         assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol)
