@@ -1,0 +1,101 @@
+"""Property tests (hypothesis) for the host-side layout builders: for ANY small CSR shape -- empty rows,
+one column, duplicate and unsorted columns, a row longer than everything else, rows that start anywhere
+in rowstr -- each builder either declines (-2) or produces a layout whose CPU emulation (the same walk
+the kernel does, tests/test_plan.py) reproduces y = A x within the reordering bound.  No GPU needed."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+import matgen
+from test_plan import lanes_emulate, striped_emulate, tiled_emulate
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    return pkg.Backend().lib
+
+
+@st.composite
+def csr_shapes(draw):
+    rows = draw(st.integers(1, 400))
+    cols = draw(st.sampled_from([1, 2, 17, 300, 5000, 9000, 20000]))
+    kind = draw(st.sampled_from(["uniform", "skewed", "mostly_empty", "one_long"]))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        lens = rng.integers(0, min(cols, 40) + 1, rows)
+    elif kind == "skewed":
+        lens = np.minimum((rng.pareto(1.2, rows) * 3).astype(np.int64), min(cols, 3000))
+    elif kind == "mostly_empty":
+        lens = np.where(rng.random(rows) < 0.8, 0, rng.integers(1, min(cols, 10) + 1, rows))
+    else:
+        lens = rng.integers(0, min(cols, 6) + 1, rows)
+        lens[rng.integers(0, rows)] = min(cols, 2500)
+    distinct = draw(st.booleans())
+    sort_cols = draw(st.booleans())
+    if distinct:
+        lens = np.minimum(lens, cols)
+    rs, ci, a = matgen.csr_from_lengths(rng, [int(v) for v in lens], cols, np.float64, sort_cols=sort_cols,
+                                        distinct=distinct)
+    return rs, ci, a, seed
+
+
+def reference(rs, ci, a, x):
+    """native-impl.c:1-12 in numpy: left to right per row; plus sum |a x| for the tolerance."""
+    rows = rs.size - 1
+    y = np.zeros(rows)
+    ab = np.zeros(rows)
+    for r in range(rows):
+        lo, hi = rs[r] - 1, rs[r + 1] - 1
+        acc = 0.0
+        for j in range(lo, hi):
+            acc += a[j] * x[ci[j] - 1]
+        y[r] = acc
+        ab[r] = np.abs(a[lo:hi] * x[ci[lo:hi] - 1]).sum()
+    return y, ab
+
+
+COMMON = dict(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large,
+                                                                   HealthCheck.function_scoped_fixture])
+
+
+def check(rc_res, rs, ci, a, x, extra_terms):
+    rc, res = rc_res
+    if rc == -2:
+        return
+    assert rc == 0
+    y = res[0]
+    y_ref, ab = reference(rs, ci, a, x)
+    tol = (np.diff(rs) + extra_terms + 4) * 2.0 ** -53 * ab
+    assert np.all(np.abs(y - y_ref) <= tol + 1e-300)
+
+
+@settings(**COMMON)
+@given(csr_shapes())
+def test_striped_layout_on_any_shape(lib, shape):
+    rs, ci, a, seed = shape
+    if ci.size == 0:
+        return
+    x = np.random.default_rng(seed + 1).standard_normal(int(ci.max()))
+    check(striped_emulate(lib, rs, ci, a, x), rs, ci, a, x, 8)
+
+
+@settings(**COMMON)
+@given(csr_shapes())
+def test_lanes_layout_on_any_shape(lib, shape):
+    rs, ci, a, seed = shape
+    if ci.size == 0:
+        return
+    x = np.random.default_rng(seed + 2).standard_normal(int(ci.max()))
+    check(lanes_emulate(lib, rs, ci, a, x), rs, ci, a, x, 8)
+
+
+@settings(**COMMON)
+@given(csr_shapes())
+def test_tiled_layout_on_any_shape(lib, shape):
+    rs, ci, a, seed = shape
+    if ci.size == 0:
+        return
+    x = np.random.default_rng(seed + 3).standard_normal(int(ci.max()))
+    check(tiled_emulate(lib, rs, ci, a, x, target_blocks=7), rs, ci, a, x, 8)
