@@ -592,3 +592,22 @@ def test_non_finite_x_entries_stay_in_the_rows_that_reference_them(pkg, backend,
             assert_close_rows(y[~touched], y_ref[~touched], absum[~touched], np.diff(rs)[~touched], np.float64, tag)
     finally:
         m.close()
+
+
+def test_all_plans_on_arbitrary_shapes(pkg, backend, oracle):
+    """hypothesis-drawn CSR shapes (empty rows, one column, duplicate / unsorted columns, one row far longer
+    than the rest, up to 20000 columns = several stripes) through every plan on the GPU, against the oracle."""
+    from hypothesis import HealthCheck, given, settings
+    from test_layout_properties import csr_shapes
+
+    @settings(max_examples=200, deadline=None, derandomize=True,
+              suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+    @given(csr_shapes())
+    def run(shape):
+        rs, ci, a, seed = shape
+        if ci.size == 0:
+            return
+        x = np.random.default_rng(seed + 9).standard_normal(int(ci.max()))
+        check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, all_plans(pkg), "drawn shape seed %d" % seed)
+
+    run()
