@@ -136,9 +136,12 @@ int spmv_hip_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t 
 int spmv_hip_memset(int device, void *dst_dev, int value, size_t bytes);
 int spmv_hip_synchronize(int device);
 
-/* Experiment switches for the kernels: key 0 = XCD-contiguous block order (default 1),
- * key 1 = non-temporal loads of a/colidx (default 0), key 2 = waves per workgroup of the TILED
- * kernel for matrices created afterwards (8 default, 16).  Not a stable interface. */
+/* Experiment switches used by tools/kbench.py (not a stable interface; they affect matrices and
+ * plans created afterwards): 0 XCD-contiguous block order of k_stream (default 1); 1 non-temporal
+ * loads of a/colidx (0); 2-4 TILED geometry (waves per workgroup, LDS bytes per stripe, workgroups
+ * aimed for); 5 register sets of k_tiled / k_striped / k_lanes; 7-10 STRIPED / LANES geometry (LDS
+ * bytes per stripe 65536|131072, waves per workgroup 8|16, workgroups aimed for, entries per lane
+ * per sub-window 4|8). */
 void spmv_hip_set_tuning(int key, int value);
 
 /* ---- ABI-path control ------------------------------------------------------ */

@@ -47,7 +47,6 @@ namespace {
 /* ---- tuning switches (set through spmvk_set_tuning; experiments only) ------- */
 int g_tune_xcd = 1;     /* give each XCD a contiguous range of row blocks        */
 int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx        */
-int g_tune_tile_dbg = 0; /* timing-only ablation bits for k_tiled (results are then wrong) */
 int g_tune_tile_k = 0;  /* register sets of k_tiled (2,4,6,8; default 4) / k_striped (2,3,4; default 2) */
 
 /* ---- 16-byte vector types --------------------------------------------------- */
@@ -406,7 +405,7 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_tiled(const int *__restrict__ w
                                                        const unsigned short *__restrict__ pcol,
                                                        const T *__restrict__ pval,
                                                        const T *__restrict__ x, T *__restrict__ y,
-                                                       int rows, int cols, int S, int RW, int dbg)
+                                                       int rows, int cols, int S, int RW)
 {
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E;
@@ -496,8 +495,7 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_tiled(const int *__restrict__ w
         abs_e = q + ns_e;
         q_e = q + n;
         if (s + 1 < S) {
-            if (!(dbg & 1))
-                x_fetch(s + 1);
+            x_fetch(s + 1);
             sg += RW + 1;
             ns_s = sg[sl];
             ns_e = sg[sl1];
@@ -505,13 +503,12 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_tiled(const int *__restrict__ w
     };
     auto end_stripe = [&]() {
         q += (n + 7) & ~7;
-        if (s + 1 < S && !(dbg & 1)) {
+        if (s + 1 < S) {
             x_store((s + 1) & 1); /* that buffer was last read in stripe s-1, which every wave
                                      left before the previous barrier */
             tail_fix(s + 1);
         }
-        if (!(dbg & 8))
-            wg_barrier_lds();
+        wg_barrier_lds();
         ++s;
     };
     begin_stripe();
@@ -529,14 +526,14 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_tiled(const int *__restrict__ w
                     T p[EPL];
 #pragma unroll
                     for (int k = 0; k < EPL; ++k)
-                        p[k] = cur.v[k] * ((dbg & 4) ? (T)cur.col(k) : xt[cur.col(k) & (W - 1)]);
+                        p[k] = cur.v[k] * xt[cur.col(k) & (W - 1)];
 #pragma unroll
                     for (int k = 0; k < EPL; ++k)
                         s_p[w][lane * EPL + k] = p[k];
                     __builtin_amdgcn_wave_barrier(); /* LDS ops of one wave complete in issue order */
                     const int lo = (abs_s > sb ? abs_s : sb) - sb;
                     const int hi = (abs_e < sb + SUB ? abs_e : sb + SUB) - sb;
-                    int k = (dbg & 2) ? hi : lo;
+                    int k = lo;
                     for (; k + 4 <= hi; k += 4) {
                         const T p0 = s_p[w][k], p1 = s_p[w][k + 1], p2 = s_p[w][k + 2], p3 = s_p[w][k + 3];
                         acc = acc + p0;
@@ -1198,8 +1195,6 @@ void spmvk_set_tuning(int key, int value)
         g_tune_nt = value;
     else if (key == 5 && value >= 0 && value <= 8)
         g_tune_tile_k = value;
-    else if (key == 6)
-        g_tune_tile_dbg = value;
 }
 
 int spmvk_ordered(const spmv_dev_csr *m, const void *x, void *y, void *stream)
@@ -1282,8 +1277,7 @@ int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream)
 #define SPMV_LT(T, R)                                                                                  \
     hipLaunchKernelGGL((k_tiled<T, SPMV_TILE_WPB, R, SPMV_TILE_LDS_BYTES>), dim3(t->B),                \
                        dim3(SPMV_TILE_WPB * 64), 0, st, t->wptr, t->seg, t->col,                       \
-                       (const T *)t->val, (const T *)x, (T *)y, t->rows, t->cols, t->S, t->RW,         \
-                       g_tune_tile_dbg)
+                       (const T *)t->val, (const T *)x, (T *)y, t->rows, t->cols, t->S, t->RW)
 #define SPMV_LTK(T)                                                                                    \
     do {                                                                                               \
         if (g_tune_tile_k == 2)                                                                        \

@@ -55,7 +55,6 @@ def main():
     ap.add_argument("--xbytes", type=int, default=32768, help="bytes of x per LDS stripe of the TILED kernel")
     ap.add_argument("--blocks", type=int, default=0, help="TILED workgroups aimed for (0 = default 512)")
     ap.add_argument("--tk", type=int, default=0, help="TILED: 256-entry sub-windows per register window")
-    ap.add_argument("--dbg", type=int, default=0, help="TILED timing ablation bits (1 no x stage, 2 no reduce, 4 no gather, 8 no barrier)")
     ap.add_argument("--sx", type=int, default=131072, help="STRIPED: bytes of x per stripe (65536|131072)")
     ap.add_argument("--swpb", type=int, default=16, help="STRIPED: waves per workgroup (8|16)")
     ap.add_argument("--sepl", type=int, default=4, help="STRIPED: entries per lane per sub-window (4|8)")
@@ -69,7 +68,6 @@ def main():
     be.set_tuning(3, args.xbytes)
     be.set_tuning(4, args.blocks)
     be.set_tuning(5, args.tk)
-    be.set_tuning(6, args.dbg)
     be.set_tuning(7, args.sx)
     be.set_tuning(8, args.swpb)
     be.set_tuning(9, args.swgs)
