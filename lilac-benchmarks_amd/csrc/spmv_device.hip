@@ -253,6 +253,28 @@ int spmvd_stream_sync(int device)
     return 0;
 }
 
+void *spmvd_host_devptr(void *pinned_host)
+{
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, pinned_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return d;
+}
+
+int spmvd_copy_words_async(int device, void *dst_dev, const void *src_devptr, size_t bytes)
+{
+    if (use_device(device))
+        return -1;
+    int rc = spmvk_copy_words(dst_dev, src_devptr, bytes, g_dev[device].stream);
+    if (rc) {
+        spmv_set_error("copy kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return -1;
+    }
+    return 0;
+}
+
 /* ---- matrices ------------------------------------------------------------------- */
 
 static void free_plans(spmv_hip_matrix *m)

@@ -42,6 +42,8 @@
  *                      matrix should call spmv_hip_release() first (or use compare/pointer/off),
  *                      because recycled heap pages would still be read-only for system calls.
  *                      compare: no page protection, every call compares the arrays byte for byte.
+ *   SPMV_HIP_ZEROCOPY = 1 (default) | 0     vectors up to 1 MB cross PCIe through kernels
+ *                                           reading / writing pinned host memory instead of DMA
  *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped | lanes
  *   SPMV_HIP_DEVICES = number of GPUs to row-partition over (default 1; "all")
  *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
@@ -112,7 +114,7 @@ typedef struct slot {
 
 static struct {
     int inited;
-    int cache, pin, stats, verbose;
+    int cache, pin, stats, verbose, zero_copy;
     int plan, plan_param;
     int ndev, nparts, nslots;
     long page;
@@ -411,6 +413,7 @@ static void lazy_init(void)
         else if (strcmp(v, "auto"))
             die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped|lanes", v);
     }
+    G.zero_copy = env_int("SPMV_HIP_ZEROCOPY", 1);
     G.stats = env_int("SPMV_HIP_STATS", 0);
     G.verbose = env_int("SPMV_HIP_VERBOSE", 0);
     G.nslots = env_int("SPMV_HIP_CACHE_SLOTS", 4);
@@ -623,6 +626,52 @@ static int use_in_place(const void *p, size_t bytes)
     return 0;
 }
 
+/* Is [p, p+bytes) pinned where it lies (static storage under auto, anything under register)? */
+static int pinned_in_place(const void *p, size_t bytes)
+{
+    if (G.pin == PIN_REGISTER || (G.pin == PIN_AUTO && has_static_storage(p, bytes)))
+        return ensure_registered(p, bytes);
+    return 0;
+}
+
+/*
+ * Small vectors: the DMA path costs two engine set-ups and 35 us for a class-A-sized round trip; a
+ * copy kernel that reads x out of pinned host memory and kernels that write y straight into pinned
+ * host memory do it in 19 us (profiles/r01_xferbench_pcie_round_trip.log).  Through the whole ABI:
+ * NPB class A 38.5 -> 26.9 us per call, class B (600-KB vectors) -6 %, class C (1.2 MB) no gain, and
+ * from 4 MB up the DMA engines win: the limit is 1 MB, above it the regular path below is used.  Pinned = the caller's static vector registered
+ * in place, else our staging buffer.  Returns 0 when the call was served this way.
+ */
+#define ZERO_COPY_MAX_BYTES ((size_t)1 << 20)
+
+static int harness_zero_copy(slot *sl, void *ov, const void *iv, size_t xbytes, size_t ybytes)
+{
+    if (!G.zero_copy || sl->nparts != 1 || G.pin == PIN_PAGEABLE || G.stats >= 2 || xbytes > ZERO_COPY_MAX_BYTES ||
+        ybytes > ZERO_COPY_MAX_BYTES || (xbytes & 3) || ((uintptr_t)iv & 3))
+        return -1;
+    void *xsrc = (void *)(uintptr_t)iv;
+    if (!pinned_in_place(iv, xbytes)) {
+        xsrc = stage_buf(&G.xstage, &G.xstage_n, xbytes);
+        memcpy(xsrc, iv, xbytes);
+    }
+    void *ydst = ov;
+    int y_staged = 0;
+    if (!pinned_in_place(ov, ybytes)) {
+        ydst = stage_buf(&G.ystage, &G.ystage_n, ybytes);
+        y_staged = 1;
+    }
+    void *xdev = spmvd_host_devptr(xsrc), *ydev = spmvd_host_devptr(ydst);
+    if (!xdev || !ydev)
+        return -1; /* not mapped into the device's address space: the DMA path takes the call */
+    const int dev = sl->part_dev[0];
+    CHECK(spmvd_copy_words_async(dev, sl->dx[0], xdev, xbytes));
+    CHECK(spmv_hip_spmv_device(sl->part[0], sl->dx[0], ydev, NULL));
+    CHECK(spmvd_stream_sync(dev));
+    if (y_staged)
+        memcpy(ov, ydst, ybytes);
+    return 0;
+}
+
 /* ---------------------------------------------------------------- the call */
 
 static void *harness(void *ov, const void *a, const void *iv, const int *rowstr, const int *colidx,
@@ -670,6 +719,13 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
     const size_t ybytes = (size_t)rows * elem;
     const int detailed = G.stats >= 2;
     double t0 = spmv_now(), t1;
+
+    if (harness_zero_copy(sl, ov, iv, xbytes, ybytes) == 0) {
+        G.st.calls++;
+        G.st.t_total += spmv_now() - t_in;
+        pthread_mutex_unlock(&g_mu);
+        return NULL;
+    }
 
     /* x: host -> every part's device (libspmv/gpu.c:264) */
     const void *xsrc = iv;

@@ -215,11 +215,11 @@ int spmvd_spmv_dot(struct spmv_hip_matrix *m, const void *x_dev, void *y_dev, vo
 /* dotv != NULL: also dot_part[b] = sum over rows [256 b, 256 b + 256) of y[r] * dotv[r] */
 int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream, const void *dotv,
                   void *dot_part);
-/* analysis: max(colidx[0..nnz)) -> *d_out (int, device), must be zeroed first */
 /* d_out[0] = max(colidx), d_out[1] = min(colidx); the caller presets {0, INT_MAX} */
 int spmvk_colrange(const int *colidx, int64_t nnz, int *d_out, void *stream);
 /* rowptr0[i] = rowstr[i] - rowstr[0] on device (in place allowed) */
 int spmvk_rebase(int *rowptr, int n_plus_1, int base, void *stream);
+int spmvk_copy_words(void *dst, const void *src, size_t bytes, void *stream);
 
 /* ---- HIP-side helpers for the C host file (spmv_device.hip) ------------------ */
 void *spmvd_host_alloc(size_t bytes);            /* pinned host memory */
@@ -229,6 +229,10 @@ void spmvd_host_unregister(void *p);
 int spmvd_copy_h2d_async(int device, void *dst_dev, const void *src, size_t bytes);
 int spmvd_copy_d2h_async(int device, void *dst, const void *src_dev, size_t bytes);
 int spmvd_stream_sync(int device);
+/* zero-copy: the device-side address of pinned host memory (hipHostMalloc'ed or registered), NULL
+ * when it has none; and a word copy kernel on the device's stream whose source may be such memory */
+void *spmvd_host_devptr(void *pinned_host);
+int spmvd_copy_words_async(int device, void *dst_dev, const void *src_devptr, size_t bytes);
 
 /* ---- misc ------------------------------------------------------------------- */
 /* Host threads for the one-time layout conversions (spmv_plan.c): fn(lo, hi, ctx) over [0, n) in

@@ -1126,6 +1126,14 @@ __global__ void __launch_bounds__(SPMV_WG) k_colrange(const int *__restrict__ co
     }
 }
 
+/* word copy; src may be pinned host memory mapped into the device's address space (zero-copy) */
+__global__ void __launch_bounds__(SPMV_WG) k_copy_words(unsigned int *__restrict__ dst,
+                                                        const unsigned int *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * SPMV_WG + threadIdx.x; i < n; i += (size_t)gridDim.x * SPMV_WG)
+        dst[i] = src[i];
+}
+
 __global__ void __launch_bounds__(SPMV_WG) k_rebase(int *__restrict__ rowptr, int n, int base)
 {
     const int i = blockIdx.x * SPMV_WG + threadIdx.x;
@@ -1422,6 +1430,19 @@ int spmvk_colrange(const int *colidx, int64_t nnz, int *d_out, void *stream)
     int grid = (int)(want < 2048 ? want : 2048);
     hipLaunchKernelGGL(k_colrange, dim3(grid), dim3(SPMV_WG), 0, (hipStream_t)stream, colidx,
                        (long long)nnz, d_out);
+    return launch_status();
+}
+
+int spmvk_copy_words(void *dst, const void *src, size_t bytes, void *stream)
+{
+    const size_t n = bytes / 4;
+    if (n == 0)
+        return 0;
+    size_t grid = (n + SPMV_WG - 1) / SPMV_WG;
+    if (grid > 1024)
+        grid = 1024;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned int)grid), dim3(SPMV_WG), 0, (hipStream_t)stream,
+                       (unsigned int *)dst, (const unsigned int *)src, n);
     return launch_status();
 }
 
