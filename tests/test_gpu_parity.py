@@ -347,6 +347,9 @@ print("OK" if ok else "MISMATCH", s["uploads"], s["calls"], inf["plan"], inf["ro
     ({"SPMV_HIP_PLAN": "ordered"}, 2, True),                  # bit-exact mode through the ABI
     ({"SPMV_HIP_PIN": "register"}, 2, False),
     ({"SPMV_HIP_PIN": "pageable", "SPMV_HIP_PLAN": "vector:32"}, 2, False),
+    ({"SPMV_HIP_ZEROCOPY": "0"}, 2, False),                   # small vectors through the DMA path as well
+    ({"SPMV_HIP_ZEROCOPY": "0", "SPMV_HIP_PIN": "staging", "SPMV_HIP_PLAN": "striped"}, 2, False),
+    ({"SPMV_HIP_PLAN": "lanes", "SPMV_HIP_BUILD_THREADS": "3"}, 2, False),
 ])
 def test_abi_policies_in_a_fresh_process(env, uploads, exact):
     code = ABI_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__), exact="True" if exact else "False")
