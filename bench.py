@@ -140,7 +140,12 @@ def main():
     barrier()
 
     nnz_total = float(m.nnz)
+    rank_ms = None
     if dist is not None:
+        mine = torch.zeros(n_gpus, dtype=torch.float64, device=red_dev)
+        mine[rank] = elapsed * 1e3 / args.steps
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)  # every rank's own ms per step, for the balance of the partition
+        rank_ms = [round(float(v), 6) for v in mine.tolist()]
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -196,6 +201,7 @@ def main():
             "launches_per_step": info["n_launches"],
             "parallelism": "1 GPU" if n_gpus == 1 else
                            "block-row partition over %d GPUs (equal nnz), x replicated, no collective" % n_gpus,
+            "rank_ms_per_step": rank_ms,
         },
         "roofline": {
             "bound": "hbm",
