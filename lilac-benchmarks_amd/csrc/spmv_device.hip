@@ -512,6 +512,18 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     /* most (row, stripe) pairs are empty: the columns are local to the rows, x gathers already
      * hit in cache and the STREAM kernel is the better plan (measured: 73 us vs 133 us) */
     m->striped_mostly_filler = rc == 0 && th.n_dummies * 2 > (int64_t)th.S * m->rows;
+    if (rc == 0 && th.n_waves > 0) {
+        /* a (row, stripe) segment is never split between waves: one dense row makes one wave per stripe
+         * run many times longer than the rest, and the kernel as long as that wave.  STREAM cuts long
+         * rows into segments; leave such matrices to it. */
+        int64_t longest = 0;
+        for (int i = 0; i < th.n_waves; ++i) {
+            const int64_t len = (int64_t)th.wptr[i + 1] - th.wptr[i];
+            longest = len > longest ? len : longest;
+        }
+        if (longest * th.n_waves > 2 * th.n_packed + 256 * (int64_t)th.n_waves * th.EPL)
+            m->striped_mostly_filler = true; /* same consequence: AUTO declines */
+    }
     if (auto_choice && m->striped_mostly_filler) {
         spmv_striped_free(&th);
         rc = -2;

@@ -1088,19 +1088,24 @@ __global__ void __launch_bounds__(SPMV_WG) k_long(const int *__restrict__ seg,
     }
 }
 
+/* One wavefront per long row: lane l adds the row's segment sums l, l+64, ... in that order, then a
+ * fixed 64-lane tree.  (A dense row of 10^8 nonzeros has 49 000 segment sums; one thread adding them
+ * one after the other would take milliseconds.) */
 template <typename T>
 __global__ void __launch_bounds__(64) k_long_finish(const int *__restrict__ lrow,
                                                     const T *__restrict__ partials,
                                                     T *__restrict__ y, int nlrow)
 {
-    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.x, lane = threadIdx.x;
     if (k >= nlrow)
         return;
     const int row = lrow[3 * k], p0 = lrow[3 * k + 1], p1 = lrow[3 * k + 2];
     T t = (T)0;
-    for (int p = p0; p < p1; ++p)
+    for (int p = p0 + lane; p < p1; p += 64)
         t += partials[p];
-    y[row] = t;
+    t = group_sum<T, 64>(t);
+    if (lane == 63)
+        y[row] = t;
 }
 
 /* ================================ analysis ====================================== */
@@ -1263,13 +1268,13 @@ int spmvk_long(const spmv_dev_csr *m, const int *seg, int nseg, const int *lrow,
         hipLaunchKernelGGL(k_long<double>, dim3(nseg), dim3(SPMV_WG), 0, st, seg, m->colidx,
                            (const double *)m->val, xm1_of<double>(x), (double *)y, (double *)partials);
         if (nlrow > 0)
-            hipLaunchKernelGGL(k_long_finish<double>, dim3((nlrow + 63) / 64), dim3(64), 0, st, lrow,
+            hipLaunchKernelGGL(k_long_finish<double>, dim3(nlrow), dim3(64), 0, st, lrow,
                                (const double *)partials, (double *)y, nlrow);
     } else {
         hipLaunchKernelGGL(k_long<float>, dim3(nseg), dim3(SPMV_WG), 0, st, seg, m->colidx,
                            (const float *)m->val, xm1_of<float>(x), (float *)y, (float *)partials);
         if (nlrow > 0)
-            hipLaunchKernelGGL(k_long_finish<float>, dim3((nlrow + 63) / 64), dim3(64), 0, st, lrow,
+            hipLaunchKernelGGL(k_long_finish<float>, dim3(nlrow), dim3(64), 0, st, lrow,
                                (const float *)partials, (float *)y, nlrow);
     }
     return launch_status();

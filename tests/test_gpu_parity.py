@@ -614,3 +614,35 @@ def test_all_plans_on_arbitrary_shapes(pkg, backend, oracle):
         check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, all_plans(pkg), "drawn shape seed %d" % seed)
 
     run()
+
+
+def test_one_dense_row_among_short_ones(pkg, backend, oracle):
+    """A row of 3 million nonzeros (1465 long-row segments, summed by one wavefront) next to 5000 short rows,
+    duplicate columns allowed: STREAM / BINNED / VECTOR / ORDERED and whatever AUTO picks."""
+    rng = np.random.default_rng(77)
+    rs, ci, a = matgen.csr_from_lengths(rng, [4] * 2500 + [3_000_000] + [7] * 2500, 200_000, np.float64,
+                                        sort_cols=False, distinct=False)
+    x = rng.standard_normal(200_000)
+    plans = [(pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_VECTOR, 64), (pkg.PLAN_AUTO, 0), (pkg.PLAN_ORDERED, 0)]
+    check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, "dense row")
+
+
+def test_auto_declines_striped_when_one_row_dominates(pkg, backend, oracle):
+    """50 000 rows of ~60 nonzeros would go to STRIPED; with one row of 2 million among them a single wave
+    per stripe would carry that row alone, so AUTO must leave the matrix to STREAM (long rows are cut up)."""
+    rng = np.random.default_rng(78)
+    lens = [60] * 25000 + [2_000_000] + [60] * 25000
+    rs, ci, a = matgen.csr_from_lengths(rng, lens, 150_000, np.float64, sort_cols=False, distinct=False)
+    x = rng.standard_normal(150_000)
+    m = backend.matrix(a, rs, ci, len(lens))
+    try:
+        assert m.info()["plan"] == pkg.PLAN_STREAM
+        y = m.spmv_host(x)
+        assert_close_rows(y, oracle.spmv(a, x, rs, ci, len(lens)), oracle.absum(a, x, rs, ci, len(lens)), np.diff(rs),
+                          np.float64, "dominant row")
+        rs2, ci2, a2 = matgen.csr_from_lengths(rng, [60] * 50001, 150_000, np.float64)
+        m2 = backend.matrix(a2, rs2, ci2, 50001)
+        assert m2.info()["plan"] == pkg.PLAN_STRIPED  # the same shape without the dominant row
+        m2.close()
+    finally:
+        m.close()
