@@ -463,6 +463,12 @@ static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_
     return 0;
 }
 
+/* spmvd_set_relayout(0): matrices created from now on get no re-laid-out copy (STRIPED / TILED) from
+ * the automatic choice -- for the ABI path when a matrix keeps changing between calls and the
+ * conversion would be paid every time (spmv_harness.c) */
+static int g_relayout = 1;
+extern "C" void spmvd_set_relayout(int on) { g_relayout = on ? 1 : 0; }
+
 /* geometry knobs of the STRIPED plan (experiments through spmv_hip_set_tuning keys 7..9) */
 static int g_stripe_xbytes = SPMV_STRIPE_XBYTES, g_stripe_wpb = SPMV_STRIPE_WPB, g_stripe_wgs = SPMV_STRIPE_TARGET_WGS,
            g_stripe_epl = SPMV_STRIPE_EPL;
@@ -827,6 +833,10 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     HIPCHK(hipStreamSynchronize(st), FAIL());
 
     spmv_plan_choose(&m->st, elem_size, m->cols, &m->plan, &m->param);
+    if (!g_relayout && (m->plan == SPMV_HIP_PLAN_TILED || m->plan == SPMV_HIP_PLAN_STRIPED)) {
+        m->plan = SPMV_HIP_PLAN_STREAM; /* the caller expects to upload this matrix again soon */
+        m->param = SPMV_STREAM_CAP;
+    }
     if (m->plan == SPMV_HIP_PLAN_TILED) {
         int rc = ensure_tiled(m, a, colidx, first, true);
         if (rc == -2) { /* not representable: the row-segment kernel takes it */

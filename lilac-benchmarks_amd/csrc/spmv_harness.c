@@ -137,6 +137,34 @@ static struct {
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 
+/*
+ * Matrices that keep changing (the caller rewrites an array between calls, as PATHSAMPLE's argument
+ * order does, Pfold.f90:219-223): the second time the same three pointers are caught changed, their
+ * uploads stop asking for a re-laid-out plan -- STRIPED costs 0.1 s per upload of a class-C-sized
+ * matrix and pays off only over hundreds of products.  Forgotten at spmv_hip_release().
+ */
+#define MAX_CHURN 16
+static struct {
+    const void *a, *rowstr, *colidx;
+    int count;
+} g_churn[MAX_CHURN];
+static int g_nchurn;
+
+static int churn_note(const void *a, const void *rowstr, const void *colidx, int bump)
+{
+    for (int i = 0; i < g_nchurn; ++i)
+        if (g_churn[i].a == a && g_churn[i].rowstr == rowstr && g_churn[i].colidx == colidx) {
+            g_churn[i].count += bump;
+            return g_churn[i].count;
+        }
+    if (!bump)
+        return 0;
+    const int i = g_nchurn < MAX_CHURN ? g_nchurn++ : 0; /* full: recycle the first entry */
+    g_churn[i].a = a, g_churn[i].rowstr = rowstr, g_churn[i].colidx = colidx;
+    g_churn[i].count = 1;
+    return 1;
+}
+
 static void die(const char *fmt, ...)
 {
     va_list ap;
@@ -331,6 +359,7 @@ void spmv_hip_release(void)
     for (int r = 0; r < G.nreg; ++r)
         spmvd_host_unregister(G.reg[r].lo);
     G.nreg = 0;
+    g_nchurn = 0;
     spmvd_host_free(G.xstage);
     spmvd_host_free(G.ystage);
     G.xstage = G.ystage = NULL;
@@ -488,6 +517,8 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
     sl->nparts = G.nparts > rows ? (rows > 0 ? rows : 1) : G.nparts;
     spmv_hip_partition_rows(rowstr, rows, sl->nparts, sl->bounds);
 
+    const int churning = G.cache == CACHE_OFF || churn_note(a, rowstr, colidx, 0) >= 2;
+    spmvd_set_relayout(!churning);
     int cols = 0;
     for (int p = 0; p < sl->nparts; ++p) {
         int dev = p % G.ndev;
@@ -502,6 +533,7 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
         spmv_hip_matrix_info(sl->part[p], &inf);
         cols = inf.cols; /* part 0 scans the whole colidx; later parts reuse it */
     }
+    spmvd_set_relayout(1);
     sl->cols = cols;
     for (int p = 0; p < sl->nparts; ++p) {
         int dev = sl->part_dev[p];
@@ -701,6 +733,7 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
         if (stale) {
             if (G.cache != CACHE_OFF) {
                 G.st.invalidations++;
+                churn_note(a, rowstr, colidx, 1);
                 if (G.verbose)
                     fprintf(stderr, "libhip-spmv: host arrays changed, dropping the device copy\n");
             }

@@ -646,3 +646,22 @@ def test_auto_declines_striped_when_one_row_dominates(pkg, backend, oracle):
         m2.close()
     finally:
         m.close()
+
+
+def test_a_matrix_that_keeps_changing_stops_being_re_laid_out(pkg, backend, oracle):
+    """The caller rewrites the values before every call (PATHSAMPLE's argument order does that): every call
+    must see the new values, and from the second detected change on the upload no longer pays for STRIPED."""
+    rng = np.random.default_rng(79)
+    rs, ci, a = matgen.csr_from_lengths(rng, [40] * 40000, 20000, np.float64)
+    x = rng.standard_normal(20000)
+    y = np.empty(40000)
+    plans = []
+    for it in range(4):
+        if it:
+            a[:] = rng.standard_normal(a.size)
+        backend.harness(y, a, x, rs, ci, 40000)
+        assert_close_rows(y, oracle.spmv(a, x, rs, ci, 40000), oracle.absum(a, x, rs, ci, 40000), np.diff(rs),
+                          np.float64, "changing matrix, call %d" % it)
+        plans.append(backend.abi_matrix_info()["plan"])
+    assert plans[:2] == [pkg.PLAN_STRIPED, pkg.PLAN_STRIPED] and plans[2:] == [pkg.PLAN_STREAM, pkg.PLAN_STREAM]
+    assert backend.stats()["uploads"] >= 4
