@@ -60,6 +60,28 @@ template <int D, bool INTER> __global__ void __launch_bounds__(512, 4) k_wavestr
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) *sink = 1;
 }
 
+// Does the Infinity Cache reward a traversal that alternates direction between passes?  Same wave-private
+// streams as k_wavestream, but pass `rev` walks every region back to front.
+template <int D> __global__ void __launch_bounds__(512, 4) k_wavestream_dir(const f4* __restrict__ p, size_t len, int rev, float* sink) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t g = (size_t)blockIdx.x * 8 + w;
+    const size_t steps = len / 64;
+    auto addr = [&](size_t t) -> size_t { return g * len + (rev ? steps - 1 - t : t) * 64 + lane; };
+    f4 ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = p[addr(d)];
+    f4 acc = 0;
+    for (size_t t = 0; t + D <= steps; t += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            acc += ring[d];
+            size_t nt = t + d + D;
+            ring[d] = p[addr(nt < steps ? nt : d)];
+        }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) *sink = 1;
+}
+
 // TILED kernel's load shapes: per step a wave takes 256 entries = 2 KiB of f64 values + 512 B of u16 columns.
 //   SHAPE 0: lane l owns entries 4l..4l+3: one 8-byte column load + two 16-byte value loads at a 32-byte lane stride
 //   SHAPE 1: lane l owns entries {2l,2l+1} and {128+2l,128+2l+1}: two dense 16-byte value loads + two 4-byte column loads
@@ -149,6 +171,13 @@ int main(int argc, char** argv) {
 #define WS(D) rep("wavestream D=" #D, time_ms([&] { k_wavestream<D, false><<<blocks, 512>>>(p, len, sink); }, 20), b2); \
               rep("wginter    D=" #D, time_ms([&] { k_wavestream<D, true><<<blocks, 512>>>(p, len, sink); }, 20), b2);
     WS(2) WS(4) WS(8) WS(12) WS(16)
+    {   // alternate direction between passes (Infinity Cache reuse?)
+        int pass = 0;
+        rep("wavestream D=4 same direction", time_ms([&] { k_wavestream_dir<4><<<blocks, 512>>>(p, len, 0, sink); }, 20), b2);
+        rep("wavestream D=4 alternating", time_ms([&] { k_wavestream_dir<4><<<blocks, 512>>>(p, len, (pass++) & 1, sink); }, 20), b2);
+        rep("wavestream D=12 same direction", time_ms([&] { k_wavestream_dir<12><<<blocks, 512>>>(p, len, 0, sink); }, 20), b2);
+        rep("wavestream D=12 alternating", time_ms([&] { k_wavestream_dir<12><<<blocks, 512>>>(p, len, (pass++) & 1, sink); }, 20), b2);
+    }
     {
         size_t steps = (size_t)36121058 / (blocks * 8) / 256;   // class-C sized: 36.1 M entries
         size_t entries = steps * blocks * 8 * 256;
