@@ -129,7 +129,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # untimed: the requested warm-up steps plus a fixed pre-warm so that a short run (--warmup 1) is not
+    # measured on a GPU that is still ramping its clocks
+    for _ in range(args.warmup + 10):
         dm.spmv_device(dx, dy)
     be.synchronize(device)
     barrier()

@@ -38,6 +38,7 @@ thread_local char g_err[512] = "";
 struct DevCtx {
     bool ready = false;
     hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr}; /* spmv_hip_time_device: created once, not inside the timed region */
 };
 DevCtx g_dev[SPMV_MAX_DEVICES];
 std::mutex g_dev_mu;
@@ -1064,9 +1065,12 @@ int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int
         return -1;
     HIPCHK(hipSetDevice(m->device), return -1);
     hipStream_t st = stream_of(m->device, stream);
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0), return -1);
-    HIPCHK(hipEventCreate(&e1), return -1);
+    DevCtx &dc = g_dev[m->device];
+    if (!dc.ev[0]) {
+        HIPCHK(hipEventCreate(&dc.ev[0]), return -1);
+        HIPCHK(hipEventCreate(&dc.ev[1]), return -1);
+    }
+    const hipEvent_t e0 = dc.ev[0], e1 = dc.ev[1];
     int rc = 0;
     HIPCHK(hipEventRecord(e0, st), rc = -1);
     for (int i = 0; i < reps && !rc; ++i)
@@ -1080,8 +1084,6 @@ int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int
     if (!rc) {
         HIPCHK(hipEventElapsedTime(ms_total, e0, e1), rc = -1);
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return rc;
 }
 
