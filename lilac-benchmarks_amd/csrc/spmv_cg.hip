@@ -50,8 +50,18 @@ __device__ __forceinline__ double sum_partials(const double *__restrict__ part, 
      * the ~150 partials was a 150-deep dependent chain and cost 15 us per kernel. */
     const int lane = threadIdx.x & 63;
     double s = 0.0;
-    for (int i = lane; i < nb; i += 64)
-        s += part[i];
+    for (int base = lane; base < nb; base += 64 * 16) { /* 16 loads in flight, added in index order */
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = base + 64 * k;
+            v[k] = i < nb ? part[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            s += v[k]; /* + 0.0 past the end changes nothing (s is never -0.0 here... and -0.0 + 0.0 = 0.0 only
+                          matters for a sum of no terms, which is 0.0 either way) */
+    }
     for (int o = 32; o; o >>= 1)
         s += __shfl_xor(s, o, 64);
     return s;
