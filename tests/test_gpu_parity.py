@@ -665,3 +665,26 @@ def test_a_matrix_that_keeps_changing_stops_being_re_laid_out(pkg, backend, orac
         plans.append(backend.abi_matrix_info()["plan"])
     assert plans[:2] == [pkg.PLAN_STRIPED, pkg.PLAN_STRIPED] and plans[2:] == [pkg.PLAN_STREAM, pkg.PLAN_STREAM]
     assert backend.stats()["uploads"] >= 4
+
+
+def test_bench_line_has_the_contract_keys():
+    """bench.py on a small class: one JSON line with the driver's keys, the roofline and cpu_baseline objects."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cls", "A", "--steps", "5", "--warmup", "1",
+                        "--cpu-iters", "1", "--npb-repeats", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-3
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["cores"] == 1
+    assert d["npb_cg"]["verified"] and d["npb_cg_device"]["verified"]
