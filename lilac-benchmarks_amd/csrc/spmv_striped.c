@@ -63,14 +63,23 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, int xbytes, int wp
     if (target_wgs < 1)
         target_wgs = 1;
     /*
-     * Widest stripes that fit LDS (fewest partial sums per row), then as many row ranges per
+     * Fewest stripes that fit LDS (fewest partial sums per row), all of the same width, then as many row ranges per
      * stripe as keep S * B within the target: every workgroup is resident at once, no tail round.
      * Narrower stripes that fill the last workgroup slots were measured and lose: on a class D row
      * block S = 125 (250 workgroups) ran 270 us against 250 us for S = 92 (184 workgroups), because
      * every extra stripe adds a row-end marker and a partial sum per row.
      */
-    const int s_min = cols > 0 ? (cols + wmax - 1) / wmax : 1;
-    int best_w = wmax, best_s = s_min, best_b = target_wgs / s_min > 0 ? target_wgs / s_min : 1;
+    int s_min = cols > 0 ? (cols + wmax - 1) / wmax : 1;
+    /* equal stripes: with full-width stripes and a remainder, the last stripe of NPB class C held
+     * 1.7 % of the nonzeros but a tenth of the workgroups */
+    const int unit = 16 / elem_size; /* stripes start on 16-byte boundaries of x */
+    int best_w = cols > 0 ? ((cols + s_min - 1) / s_min + unit - 1) / unit * unit : wmax;
+    if (best_w > wmax)
+        best_w = wmax;
+    if (best_w < unit)
+        best_w = unit;
+    s_min = cols > 0 ? (cols + best_w - 1) / best_w : 1;
+    int best_s = s_min, best_b = target_wgs / s_min > 0 ? target_wgs / s_min : 1;
     if (best_b < 1)
         best_b = 1;
     /* no point in more waves than rows */
@@ -87,6 +96,7 @@ typedef struct build_ctx {
     const void *a;
     const int *rowstr, *colidx;
     int r0, rows, cols, elem, S, W, B, WPB, EPL, G;
+    int cap;         /* elements of the kernel's LDS buffer: its last one is the fillers' zero */
     int64_t SUB;
     int32_t *cnt;    /* [S][rows] entries of row r in stripe s                               */
     int32_t *start;  /* [S][rows] position of the segment's first entry, relative to its stripe */
@@ -202,7 +212,7 @@ static void pass_fillers(int64_t lo, int64_t hi, void *vc)
         const int32_t *st = c->start + (size_t)s * c->rows;
         for (int r = 0; r < c->rows; ++r)
             if (cs[r] == 0)
-                c->t->col[c->sbase[s] + st[r]] = (uint16_t)(0x8000u | (unsigned)(c->W + 16 / c->elem - 1));
+                c->t->col[c->sbase[s] + st[r]] = (uint16_t)(0x8000u | (unsigned)(c->cap - 1));
     }
 }
 
@@ -228,6 +238,7 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
     c.r0 = r0, c.rows = rows, c.cols = cols, c.elem = elem_size;
     c.S = S, c.W = t->W, c.B = t->B, c.WPB = t->WPB, c.EPL = t->EPL;
     c.G = 16 / elem_size;        /* values per 16-byte unit */
+    c.cap = xbytes / elem_size > 32768 ? 32768 : xbytes / elem_size;
     c.SUB = 64 * (int64_t)t->EPL; /* entries per sub-window */
     c.t = t;
     int rc = -1;

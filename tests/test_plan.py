@@ -275,7 +275,7 @@ def striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6, epl=4):
             c = int(col[q])
             lc = c & 0x7fff
             if lc >= t.W:  # a filler: it multiplies with the zeroed last element of the LDS buffer, never with x
-                assert lc == t.W + 16 // a.dtype.itemsize - 1 and val[q] == 0 and c >> 15
+                assert lc == min(xbytes // a.dtype.itemsize, 32768) - 1 and val[q] == 0 and c >> 15
                 xv = a.dtype.type(0)
             elif s * t.W + lc < x.size:
                 xv = x[s * t.W + lc]
@@ -313,8 +313,10 @@ def test_striped_layout(lib, oracle, dtype):
         y, geo = res
         rc4, res4 = striped_emulate(lib, rs, ci, a, x, epl=8)
         assert rc4 == 0 and np.array_equal(res4[0], y)  # same sums whatever the sub-window size
-        assert geo["S"] == -(-int(ci.max()) // geo["W"]) and geo["W"] * a.dtype.itemsize <= 65536
-        assert geo["S"] * geo["B"] <= 6 and (geo["W"] + 16 // a.dtype.itemsize) * a.dtype.itemsize == 65536
+        unit = 16 // a.dtype.itemsize
+        assert geo["S"] == -(-int(ci.max()) // geo["W"]) and (geo["W"] + unit) * a.dtype.itemsize <= 65536
+        assert geo["S"] * geo["B"] <= 6 and geo["W"] % unit == 0
+        assert geo["W"] - -(-int(ci.max()) // geo["S"]) < unit  # equal stripes, rounded up to 16 bytes of x
         y_ref = oracle.spmv(a, x, rs, ci, rows)
         tol = (np.diff(rs) + geo["S"] + 2) * eps * oracle.absum(a, x, rs, ci, rows)
         assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol)
