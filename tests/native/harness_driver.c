@@ -1,0 +1,177 @@
+/*
+ * tests/native/harness_driver.c -- scenarios for spmv_harness.c on the mock device (mock_device.c):
+ * cache hits, write detection through page protection and through the compared edge pages, cache policies,
+ * the zero-copy path, churn, float/double side by side, degenerate shapes.  Prints "ok <scenario>" lines; any
+ * failed expectation aborts.  Run by tests/test_native_sanitizers.py, plain and under ASan/UBSan.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "spmv_harness.h"
+#include "spmv_hip.h"
+
+extern int mock_creates, mock_relayout_creates, mock_word_copies, mock_registered;
+
+#define EXPECT(c)                                                                 \
+    do {                                                                          \
+        if (!(c)) {                                                               \
+            fprintf(stderr, "%s:%d: expectation failed: %s\n", __FILE__, __LINE__, #c); \
+            abort();                                                              \
+        }                                                                         \
+    } while (0)
+
+static uint64_t st = 0x9E3779B97F4A7C15ull;
+static double rnd(void)
+{
+    st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+    return (double)(st % 2001) / 1000.0 - 1.0;
+}
+
+typedef struct csr {
+    int rows, cols;
+    int64_t nnz;
+    int *rowstr, *colidx;
+    double *a;
+} csr;
+
+static csr make(int rows, int cols, int len)
+{
+    csr m;
+    m.rows = rows, m.cols = cols, m.nnz = (int64_t)rows * len;
+    m.rowstr = (int *)malloc(((size_t)rows + 1) * sizeof(int));
+    m.colidx = (int *)malloc((size_t)m.nnz * sizeof(int));
+    m.a = (double *)malloc((size_t)m.nnz * sizeof(double));
+    for (int r = 0; r <= rows; ++r)
+        m.rowstr[r] = 1 + r * len;
+    for (int64_t j = 0; j < m.nnz; ++j) {
+        m.colidx[j] = 1 + (int)((uint64_t)(rnd() * 1e6 + 2e6) % (uint64_t)cols);
+        m.a[j] = rnd();
+    }
+    m.colidx[m.nnz - 1] = cols; /* the inferred column count */
+    return m;
+}
+
+static void check(const csr *m, const double *x, const double *y)
+{
+    for (int r = 0; r < m->rows; ++r) {
+        double acc = 0.0;
+        for (int j = m->rowstr[r] - 1; j < m->rowstr[r + 1] - 1; ++j)
+            acc += m->a[j] * x[m->colidx[j] - 1];
+        EXPECT(acc == y[r]);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const char *policy = argc > 1 ? argv[1] : "mprotect";
+    spmv_hip_stats s;
+    csr m = make(6000, 5000, 40); /* a: 1.9 MB, colidx: 960 KB: interior pages get protected */
+    double *x = (double *)malloc(5000 * sizeof(double)), *y = (double *)malloc(6000 * sizeof(double));
+    for (int i = 0; i < 5000; ++i)
+        x[i] = rnd();
+    int rows = m.rows;
+
+    spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
+    check(&m, x, y);
+    spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
+    check(&m, x, y);
+    spmv_hip_get_stats(&s);
+    EXPECT(s.calls == 2);
+    EXPECT(s.uploads == (strcmp(policy, "off") ? 1 : 2));
+    printf("ok cache hit (%s)\n", policy);
+
+    /* edit in the middle of a (an interior, protected page under mprotect) */
+    m.a[m.nnz / 2] += 1.0;
+    spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
+    spmv_hip_get_stats(&s);
+    if (!strcmp(policy, "pointer")) {
+        EXPECT(s.uploads == 1); /* gpu-unsafe.c semantics: the edit goes unnoticed */
+    } else {
+        check(&m, x, y);
+        EXPECT(s.uploads == (strcmp(policy, "off") ? 2 : 3));
+        EXPECT(strcmp(policy, "off") == 0 || s.invalidations == 1);
+    }
+    printf("ok interior edit (%s)\n", policy);
+
+    if (strcmp(policy, "pointer")) {
+        /* edit the first element of colidx's neighbour page fragment and the last of rowstr's */
+        m.a[0] -= 0.5;
+        spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
+        check(&m, x, y);
+        m.colidx[1] = m.colidx[1] % 4999 + 1;
+        spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
+        check(&m, x, y);
+        spmv_hip_get_stats(&s);
+        EXPECT(strcmp(policy, "off") == 0 || s.invalidations == 3);
+        /* the third detected change of the same arrays: uploads stop asking for the re-laid-out plan */
+        {
+            const int parts = getenv("SPMV_HIP_PARTS") ? atoi(getenv("SPMV_HIP_PARTS")) : 1;
+            EXPECT(strcmp(policy, "off") == 0 || mock_relayout_creates == 2 * parts);
+        }
+        printf("ok edge edits and churn (%s)\n", policy);
+    }
+
+    /* fewer rows through a temporary, as Pfold.f90:221 passes NMIN-1 */
+    int fewer = m.rows - 1;
+    spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &fewer);
+    for (int r = 0; r < fewer; ++r) {
+        double acc = 0.0;
+        for (int j = m.rowstr[r] - 1; j < m.rowstr[r + 1] - 1; ++j)
+            acc += m.a[j] * x[m.colidx[j] - 1];
+        EXPECT(acc == y[r]);
+    }
+    printf("ok rows as a temporary (%s)\n", policy);
+
+    /* small vectors went through the zero-copy path (copy kernel), unless switched off */
+    {
+        const char *pin = getenv("SPMV_HIP_PIN");
+        const int off = getenv("SPMV_HIP_ZEROCOPY") || getenv("MOCK_NO_DEVPTR") || (pin && !strcmp(pin, "pageable"));
+        EXPECT(off ? mock_word_copies == 0 || getenv("MOCK_NO_DEVPTR") != NULL : mock_word_copies > 0);
+    }
+
+    /* float twin next to the double matrix */
+    {
+        const int n = 300;
+        int *rs = (int *)malloc((n + 1) * sizeof(int)), *ci = (int *)malloc(n * 3 * sizeof(int));
+        float *fa = (float *)malloc(n * 3 * sizeof(float)), *fx = (float *)malloc(n * sizeof(float));
+        float *fy = (float *)malloc(n * sizeof(float));
+        for (int r = 0; r <= n; ++r)
+            rs[r] = 1 + 3 * r;
+        for (int j = 0; j < 3 * n; ++j)
+            ci[j] = 1 + (j * 7) % n, fa[j] = (float)rnd();
+        ci[3 * n - 1] = n;
+        for (int i = 0; i < n; ++i)
+            fx[i] = (float)rnd();
+        int nn = n;
+        f_spmv_harness_(fy, fa, fx, rs, ci, &nn);
+        for (int r = 0; r < n; ++r) {
+            float acc = 0.0f;
+            for (int j = rs[r] - 1; j < rs[r + 1] - 1; ++j)
+                acc += fa[j] * fx[ci[j] - 1];
+            EXPECT(acc == fy[r]);
+        }
+        spmv_hip_release(); /* before freeing arrays the cache may have protected */
+        free(rs), free(ci), free(fa), free(fx), free(fy);
+        printf("ok float twin (%s)\n", policy);
+    }
+
+    /* degenerate shapes: no rows, all rows empty */
+    {
+        int zero = 0, three = 3;
+        int rs[4] = {1, 1, 1, 1};
+        double yy[3] = {9, 9, 9}, dummy = 0;
+        int ci0 = 1;
+        spmv_harness_(yy, &dummy, &dummy, rs, &ci0, &zero);
+        EXPECT(yy[0] == 9);
+        spmv_harness_(yy, &dummy, &dummy, rs, &ci0, &three);
+        EXPECT(yy[0] == 0 && yy[1] == 0 && yy[2] == 0);
+        printf("ok degenerate shapes (%s)\n", policy);
+    }
+    spmv_hip_release();
+    free(m.rowstr), free(m.colidx), free(m.a), free(x), free(y);
+    printf("harness_driver: all scenarios passed (%s), %d uploads seen by the mock device\n", policy, mock_creates);
+    return 0;
+}

@@ -1,0 +1,125 @@
+/*
+ * tests/native/layout_fuzz.c -- the host-side layout builders (spmv_plan.c, spmv_striped.c, spmv_lanes.c,
+ * spmv_tiled.c) on a few thousand random CSR shapes, meant to be built with
+ * -fsanitize=address,undefined (tests/test_native_sanitizers.py): the builders write into arrays at computed
+ * offsets, which is exactly what a sanitizer is for.  No GPU code is linked; the two helpers the C files
+ * expect from spmv_device.hip are stubbed here.
+ */
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "spmv_internal.h"
+
+void spmv_set_error(const char *fmt, ...)
+{
+    (void)fmt;
+}
+double spmv_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint64_t rnd(void)
+{
+    rng_state ^= rng_state << 13, rng_state ^= rng_state >> 7, rng_state ^= rng_state << 17;
+    return rng_state;
+}
+
+int main(int argc, char **argv)
+{
+    const int cases = argc > 1 ? atoi(argv[1]) : 2000;
+    long built[3] = {0, 0, 0}, declined[3] = {0, 0, 0};
+    for (int t = 0; t < cases; ++t) {
+        /* mostly small shapes; every 25th is large enough for the builders' passes to split over threads */
+        const int rows = (t % 25 == 24) ? 9000 + (int)(rnd() % 30000) : 1 + (int)(rnd() % 700);
+        const int colsel[] = {1, 2, 15, 16, 17, 300, 5000, 9000, 20000, 70000};
+        const int cols = colsel[rnd() % 10];
+        const int kind = (int)(rnd() % 4);
+        const int elem = (rnd() & 1) ? 8 : 4;
+        int *rowstr = (int *)malloc(((size_t)rows + 1) * sizeof(int));
+        int64_t nnz = 0;
+        int first = 1 + (int)(rnd() % 5); /* rowstr need not start at 1 */
+        rowstr[0] = first;
+        for (int r = 0; r < rows; ++r) {
+            int len;
+            if (kind == 0)
+                len = (int)(rnd() % 41);
+            else if (kind == 1)
+                len = (rnd() % 10 < 8) ? 0 : 1 + (int)(rnd() % 10);
+            else if (kind == 2)
+                len = (rnd() % 50 == 0) ? 500 + (int)(rnd() % 2500) : (int)(rnd() % 6);
+            else
+                len = 1 + (int)(rnd() % 3);
+            nnz += len;
+            rowstr[r + 1] = first + (int)nnz;
+        }
+        const size_t total = (size_t)(first - 1) + (size_t)nnz;
+        int *colidx = (int *)malloc((total ? total : 1) * sizeof(int));
+        void *a = malloc((total ? total : 1) * (size_t)elem);
+        for (size_t j = 0; j < total; ++j) {
+            colidx[j] = 1 + (int)(rnd() % (uint64_t)cols);
+            if (elem == 8)
+                ((double *)a)[j] = (double)(rnd() % 1000) / 7.0 - 70.0;
+            else
+                ((float *)a)[j] = (float)(rnd() % 1000) / 7.0f - 70.0f;
+        }
+        /* builders take the pointers as the ABI delivers them: entry j of the arrays is at index j, the
+         * first row begins at rowstr[0] - 1 */
+        spmv_row_stats st;
+        spmv_plan_row_stats(rowstr, 0, rows, &st);
+        spmv_stream_plan sp;
+        if (spmv_plan_stream_build(rowstr, 0, rows, SPMV_STREAM_CAP - 4, SPMV_STREAM_ROWCAP, SPMV_LONG_SEG, &sp) == 0)
+            spmv_plan_stream_free(&sp);
+        spmv_bin_plan bp;
+        if (spmv_plan_bins_build(rowstr, 0, rows, SPMV_STREAM_CAP - 4, &bp) == 0)
+            spmv_plan_bins_free(&bp);
+        int bounds[9];
+        spmv_hip_partition_rows(rowstr, rows, 1 + (int)(rnd() % 8), bounds);
+
+        const int xb = (rnd() & 1) ? 65536 : 131072, wpb = (rnd() & 1) ? 8 : 16, wgs = 1 + (int)(rnd() % 40);
+        spmv_striped_host sh;
+        int rc = spmv_striped_build(a, rowstr, colidx, 0, rows, cols, elem, xb, wpb, wgs, (rnd() & 1) ? 4 : 8, &sh);
+        if (rc == 0) {
+            built[0]++;
+            spmv_striped_free(&sh);
+        } else if (rc == -2) {
+            declined[0]++;
+        } else {
+            fprintf(stderr, "striped rc=%d\n", rc);
+            return 1;
+        }
+        spmv_lanes_host lh;
+        rc = spmv_lanes_build(a, rowstr, colidx, 0, rows, cols, elem, xb, wpb, wgs, &lh);
+        if (rc == 0) {
+            built[1]++;
+            spmv_lanes_free(&lh);
+        } else if (rc == -2) {
+            declined[1]++;
+        } else {
+            fprintf(stderr, "lanes rc=%d\n", rc);
+            return 1;
+        }
+        spmv_tiled_host th;
+        rc = spmv_tiled_build(a, rowstr, colidx, 0, rows, cols, elem, 1 + (int)(rnd() % 30), &th);
+        if (rc == 0) {
+            built[2]++;
+            spmv_tiled_free(&th);
+        } else if (rc == -2) {
+            declined[2]++;
+        } else {
+            fprintf(stderr, "tiled rc=%d\n", rc);
+            return 1;
+        }
+        free(rowstr), free(colidx), free(a);
+    }
+    printf("layout_fuzz: %d cases; striped %ld built / %ld declined; lanes %ld / %ld; tiled %ld / %ld\n", cases,
+           built[0], declined[0], built[1], declined[1], built[2], declined[2]);
+    return 0;
+}
