@@ -428,6 +428,25 @@ def test_parboil_small_through_the_float_abi(pkg, backend, oracle):
     C.free(m)
 
 
+def test_parboil_medium_through_the_float_abi(pkg, backend, oracle):
+    """bcsstk18 (11 948 rows, 149 090 nonzeros after mirroring), FP32, judged by the reference's comparator
+    against the .out file it ships, and row by row against the oracle."""
+    C = pkg.callers
+    pm = os.path.join(GOLD, "parboil_medium")
+    m = C.pb_load(os.path.join(pm, "bcsstk18.mtx"))
+    vec = os.path.join(pm, "vector.bin")
+    y = C.pb_run(m, backend.harness_fn(np.float32), vec)
+    gold = np.fromfile(os.path.join(pm, "bcsstk18.mtx.out"), dtype=np.uint8)[4:].view(np.float32)
+    assert C.pb_compare(gold, y) == 0
+    rs, ci, a = m.arrays()
+    x = np.zeros(m.cols + 2, np.float32)
+    x[: m.rows] = np.fromfile(vec, np.float32)[: m.rows]
+    y_ref = C.pb_run(m, oracle.harness_fn(np.float32), vec)
+    assert_close_rows(y, y_ref, oracle.absum(a.copy(), x, rs.copy(), ci.copy(), m.rows), np.diff(rs), np.float32,
+                      "parboil medium")
+    C.free(m)
+
+
 def test_bfs_driver_distances_bit_exact(pkg, backend, oracle):
     C = pkg.callers
     for g in (C.bfs_read(os.path.join(GOLD, "bfs", "input.mtx")), C.graph_rmat(13, 8, 5), C.graph_grid2d(64, 48)):
