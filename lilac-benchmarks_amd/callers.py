@@ -126,9 +126,18 @@ def pagerank(m, harness_fn, iters, d=0.85, prepare=True):
     return x[: m.rows], err
 
 
-def pb_load(mtx_path):
+def mm_read(path):
+    """Matrix Market coordinate (real / integer / pattern, general / symmetric) -> CsrD."""
+    m = CsrD()
+    _chk(lib().mm_read_csr(path.encode(), ctypes.byref(m)), "mm_read_csr(%s)" % path)
+    return m
+
+
+def pb_load(mtx_path, binary=False):
+    """parboil's converter as its main.c calls it (mirrored = 1); `binary` = the file has no value column
+    (the converter's own flag for pattern matrices, convert_dataset.c:93-100)."""
     m = CsrF()
-    _chk(lib().pb_coo_to_csr(mtx_path.encode(), 1, 0, ctypes.byref(m)), "pb_coo_to_csr")
+    _chk(lib().pb_coo_to_csr(mtx_path.encode(), 1, 1 if binary else 0, ctypes.byref(m)), "pb_coo_to_csr")
     return m
 
 

@@ -122,3 +122,48 @@ def test_cli_drivers_with_the_oracle_backend(pkg, oracle):
     out = subprocess.run([pkg.lib_path("spmvdrv"), "sb", oracle.path, "8", "3"], stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=120)
     assert out.returncode == 0 and "spmv_calls=201" in out.stdout and ",SparseBench,oracle,8," in out.stdout
+
+
+def _parse_mm(path):
+    """Independent Matrix Market reader (test side): dense matrix of a small coordinate file."""
+    with open(path) as f:
+        head = f.readline().lower()
+        line = f.readline()
+        while line.startswith("%"):
+            line = f.readline()
+        rows, cols, n = (int(v) for v in line.split())
+        dense = np.zeros((rows, cols))
+        for _ in range(n):
+            p = f.readline().split()
+            r, c = int(p[0]) - 1, int(p[1]) - 1
+            v = 1.0 if "pattern" in head else float(p[2])
+            dense[r, c] += v
+            if "symmetric" in head and r != c:
+                dense[c, r] += v
+    return dense
+
+
+@pytest.mark.parametrize("name,shape,nnz", [("jgl009.mtx", (9, 9), 50), ("fidapm05.mtx", (42, 42), 520)])
+def test_matrix_market_samples_of_the_reference_converter(pkg, oracle, name, shape, nnz):
+    """The two sample inputs next to parboil's convert_dataset.c (a `pattern general` and a `real general` file):
+    our readers build the CSR the dense product confirms."""
+    C = pkg.callers
+    path = os.path.join(GOLD, "mm_samples", name)
+    dense = _parse_mm(path)
+    assert dense.shape == shape
+    m = C.mm_read(path)
+    rs, ci, a = m.arrays()
+    assert (m.rows, m.nnz) == (shape[0], nnz) and rs[0] == 1 and rs[-1] == nnz + 1
+    x = np.random.default_rng(9).standard_normal(shape[1])
+    y = oracle.spmv(a.copy(), x, rs.copy(), ci.copy(), m.rows)
+    assert np.allclose(y, dense @ x, rtol=1e-13, atol=1e-13)
+    C.free(m)
+    # parboil's own loader mirrors every off-diagonal entry whatever the header says (main.c passes
+    # mirrored = 1 to the converter, convert_dataset.c:82-112): FP32, stable sort by row
+    mf = C.pb_load(path, binary=name == "jgl009.mtx")  # the pattern file has no value column
+    rsf, cif, af = mf.arrays()
+    mirrored = dense + (dense - np.diag(np.diag(dense))).T
+    assert mf.rows == shape[0] and mf.nnz == nnz + int(np.count_nonzero(dense - np.diag(np.diag(dense))))
+    yf = oracle.spmv(af.copy(), x.astype(np.float32), rsf.copy(), cif.copy(), mf.rows)
+    assert np.allclose(yf, mirrored @ x, rtol=2e-5, atol=2e-4)
+    C.free(mf)
