@@ -295,14 +295,6 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
     if (st->rows <= 0)
         return;
     /*
-     * STRIPED (2-D: one stripe of x resident in LDS per workgroup) when the gathers would
-     * otherwise miss: x much larger than a stripe is not required, but every (row, stripe) segment
-     * must hold a few nonzeros on average, or the row-end markers and per-stripe partial sums cost
-     * more than the gathers they save.  Matrices whose columns are local to the rows (banded)
-     * fail the builder's filler test and stay on STREAM.  Measured on NPB class C: STREAM 224 us,
-     * TILED 122 us (bit-exact), STRIPED 82 us.
-     */
-    /*
      * Tiny matrices (a few dozen row blocks at most) are pure launch latency; one wavefront per
      * row has no LDS phase and no barrier and finishes in 2.6 us where STREAM takes 4.0
      * (NPB class S; profiles/r01_kbench20_dispatch_table.log).  Not with a row long enough to
@@ -311,6 +303,21 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
     if (st->nnz <= 131072 && st->rows <= 8192 && st->max_len <= 4096) {
         *plan = SPMV_HIP_PLAN_VECTOR;
         *param = 64;
+        return;
+    }
+    /*
+     * STRIPED (2-D: one stripe of x resident in LDS per workgroup) when the gathers would
+     * otherwise miss: x much larger than a stripe is not required, but every (row, stripe) segment
+     * must hold a few nonzeros on average, or the row-end markers and per-stripe partial sums cost
+     * more than the gathers they save.  Matrices whose columns are local to the rows (banded)
+     * fail the builder's filler test and stay on STREAM.  Measured on NPB class C: STREAM 224 us,
+     * TILED 122 us (bit-exact), STRIPED 80 us; worth it from about 2 M nonzeros.
+     */
+    const int W = SPMV_STRIPE_XBYTES / elem_size - 16 / elem_size; /* spmv_striped_geometry */
+    const int S = cols > 0 ? (cols + W - 1) / W : 1;
+    if (st->nnz >= 2000000 && st->rows >= 1024 && cols >= W / 2 && S <= 128 && st->mean_len / (double)S >= 4.0) {
+        *plan = SPMV_HIP_PLAN_STRIPED; /* 20 000 rows x 250 nonzeros: 13 us against 26 us for STREAM */
+        *param = W;
         return;
     }
     /*
@@ -323,12 +330,6 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
         *plan = SPMV_HIP_PLAN_VECTOR;
         *param = st->rows <= 8192 ? 64 : 16;
         return;
-    }
-    const int W = SPMV_STRIPE_XBYTES / elem_size - 16 / elem_size; /* spmv_striped_geometry */
-    const int S = cols > 0 ? (cols + W - 1) / W : 1;
-    if (st->rows >= 32768 && cols >= W / 2 && S <= 128 && st->mean_len / (double)S >= 4.0) {
-        *plan = SPMV_HIP_PLAN_STRIPED;
-        *param = W;
     }
 }
 

@@ -671,7 +671,7 @@ def test_a_matrix_that_keeps_changing_stops_being_re_laid_out(pkg, backend, orac
     """The caller rewrites the values before every call (PATHSAMPLE's argument order does that): every call
     must see the new values, and from the second detected change on the upload no longer pays for STRIPED."""
     rng = np.random.default_rng(79)
-    rs, ci, a = matgen.csr_from_lengths(rng, [40] * 40000, 20000, np.float64)
+    rs, ci, a = matgen.csr_from_lengths(rng, [60] * 40000, 20000, np.float64)  # 2.4 M nonzeros: STRIPED territory
     x = rng.standard_normal(20000)
     y = np.empty(40000)
     plans = []
