@@ -302,20 +302,21 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
      */
     if (st->nnz <= 131072 && st->rows <= 8192 && st->max_len <= 4096) {
         *plan = SPMV_HIP_PLAN_VECTOR;
-        *param = 64;
+        *param = st->mean_len >= 32.0 || st->max_len > 512 ? 64 : (st->mean_len >= 12.0 ? 16 : 4);
         return;
     }
     /*
      * STRIPED (2-D: one stripe of x resident in LDS per workgroup) when the gathers would
      * otherwise miss: x much larger than a stripe is not required, but every (row, stripe) segment
-     * must hold a few nonzeros on average, or the row-end markers and per-stripe partial sums cost
-     * more than the gathers they save.  Matrices whose columns are local to the rows (banded)
+     * must hold a nonzero or two on average, or the row-end markers and per-stripe partial sums cost
+     * more than the gathers they save (512 000 rows x 64 over 32 stripes, 2 per segment: 127 us
+     * against 236 us for STREAM; below ~1.7 per segment the builder's filler limit declines).  Matrices whose columns are local to the rows (banded)
      * fail the builder's filler test and stay on STREAM.  Measured on NPB class C: STREAM 224 us,
      * TILED 122 us (bit-exact), STRIPED 80 us; worth it from about 2 M nonzeros.
      */
     const int W = SPMV_STRIPE_XBYTES / elem_size - 16 / elem_size; /* spmv_striped_geometry */
     const int S = cols > 0 ? (cols + W - 1) / W : 1;
-    if (st->nnz >= 2000000 && st->rows >= 1024 && cols >= W / 2 && S <= 128 && st->mean_len / (double)S >= 4.0) {
+    if (st->nnz >= 2000000 && st->rows >= 1024 && cols >= W / 2 && S <= 128 && st->mean_len / (double)S >= 1.6) {
         *plan = SPMV_HIP_PLAN_STRIPED; /* 20 000 rows x 250 nonzeros: 13 us against 26 us for STREAM */
         *param = W;
         return;
@@ -326,9 +327,10 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
      * 8.3 vs 9.9 us).  Not for skewed rows: on R-MAT 2^14 a 16-lane group per row takes 27 us where
      * STREAM takes 10.
      */
-    if (st->nnz <= 4000000 && st->rows <= 32768 && st->max_len <= 4.0 * st->mean_len + 16.0 && st->mean_len >= 16.0) {
+    if (st->nnz <= 4000000 && st->rows <= (st->mean_len < 12.0 ? 131072 : 32768) &&
+        st->max_len <= 4.0 * st->mean_len + 16.0) {
         *plan = SPMV_HIP_PLAN_VECTOR;
-        *param = st->rows <= 8192 ? 64 : 16;
+        *param = st->mean_len < 12.0 ? 4 : (st->rows <= 8192 && st->mean_len >= 32.0 ? 64 : 16);
         return;
     }
 }
