@@ -65,6 +65,56 @@ def main():
                 dm.close()
                 be.free(dx)
                 be.free(dy)
+    # other structures: columns local to the rows (banded), heavy-tailed row lengths, R-MAT graphs
+    rng = np.random.default_rng(11)
+    extra = []
+    for rows, mean in ((50000, 60), (200000, 40), (1000000, 12)):
+        lens = rng.poisson(mean, rows).astype(np.int64)
+        start = np.cumsum(lens) - lens
+        k = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(start, lens)
+        ci = ((np.repeat(np.arange(rows, dtype=np.int64), lens) + k) % rows + 1).astype(np.int32)
+        rs = np.concatenate(([1], 1 + np.cumsum(lens))).astype(np.int32)
+        extra.append(("banded %dx%d" % (rows, mean), rs, ci, rng.standard_normal(ci.size)))
+    for rows, scale in ((40000, 30.0), (300000, 8.0)):
+        lens = np.minimum((rng.pareto(1.3, rows) * scale).astype(np.int64), rows // 2)
+        extra.append(("pareto %d" % rows,) + matgen.csr_from_lengths(rng, [int(v) for v in lens], rows, np.float64))
+    for sc in (15, 17, 19):
+        extra.append(("rmat%d" % sc,) + matgen.rmat_graph(20, sc, 16, np.float64, values="normal"))
+    for name, rs, ci, a in extra:
+        rows = rs.size - 1
+        dm = be.matrix(a, rs, ci, rows)
+        inf = dm.info()
+        x = np.random.default_rng(1).standard_normal(inf["cols"] + 2)
+        dx = be.malloc(x.nbytes)
+        dy = be.malloc(rows * 8 + 16)
+        be.h2d(dx, x)
+
+        def t2():
+            dm.time_device(dx, dy, 3)
+            return dm.time_device(dx, dy, 40) / 40 * 1e3
+        dm.set_plan(pkg.PLAN_AUTO, 0)
+        auto_plan = pkg.abi.PLAN_NAMES[dm.info()["plan"]]
+        auto_us = t2()
+        res = {}
+        for pname, plan, par in cand + [("binned", pkg.PLAN_BINNED, 0)]:
+            try:
+                dm.set_plan(plan, par)
+            except RuntimeError:
+                continue
+            if pname.startswith("vec") and inf["max_row_len"] > 100000:
+                continue
+            res[pname] = t2()
+        best = min(res, key=res.get)
+        flag = auto_us > 1.10 * res[best]
+        print("%-16s rows=%d nnz=%d len %d..%d | %-8s %8.2f | best %-8s %8.2f | %s%s" % (
+            name, rows, inf["nnz"], inf["min_row_len"], inf["max_row_len"], auto_plan, auto_us, best, res[best],
+            " ".join("%s=%.1f" % kv for kv in sorted(res.items())),
+            "   <-- %.0f %% behind" % ((auto_us / res[best] - 1) * 100) if flag else ""), flush=True)
+        if flag:
+            worst.append(name)
+        dm.close()
+        be.free(dx)
+        be.free(dy)
     print("%d shape(s) where AUTO is more than 10 %% behind the best plan" % len(worst))
 
 
