@@ -516,9 +516,11 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
                                                host_col + shift, 0, m->rows, m->cols, m->elem, g_stripe_xbytes,
                                                g_stripe_wpb, g_stripe_wgs, g_stripe_epl, &th);
     free(tmp_a), free(tmp_c);
-    /* most (row, stripe) pairs are empty: the columns are local to the rows, x gathers already
-     * hit in cache and the STREAM kernel is the better plan (measured: 73 us vs 133 us) */
-    m->striped_mostly_filler = rc == 0 && th.n_dummies * 2 > (int64_t)th.S * m->rows;
+    /* many (row, stripe) pairs are empty: the columns are local to the rows, x gathers already
+     * hit in cache and the STREAM kernel is the better plan (measured: 73 us vs 133 us; with only two
+     * stripes a banded matrix leaves just under half of the pairs empty, hence 40 %, while scattered
+     * columns at the 1.6-per-segment limit of spmv_plan_choose leave 20 %) */
+    m->striped_mostly_filler = rc == 0 && th.n_dummies * 5 >= 2 * (int64_t)th.S * m->rows; /* 40 % of the pairs */
     if (rc == 0 && th.n_waves > 0) {
         /* a (row, stripe) segment is never split between waves: one dense row makes one wave per stripe
          * run many times longer than the rest, and the kernel as long as that wave.  STREAM cuts long

@@ -14,6 +14,7 @@ import pkgload  # noqa: E402
 
 
 def main():
+    dtype = np.float32 if "--f32" in sys.argv else np.float64
     pkg = pkgload.load_package()
     be = pkg.Backend()
     cand = [("striped", pkg.PLAN_STRIPED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec16", pkg.PLAN_VECTOR, 16),
@@ -28,12 +29,12 @@ def main():
                 cols = int(rows * cols_f)
                 if cols_f != 1.0 and (rows > 128000 or mean < 16):
                     continue
-                rs, ci, a = matgen.npb_like(7, rows, mean)
+                rs, ci, a = matgen.npb_like(7, rows, mean, dtype)
                 if cols_f != 1.0:  # spread the same pattern over more columns
                     ci = ((ci.astype(np.int64) - 1) * 8 + 1).astype(np.int32)
                 dm = be.matrix(a, rs, ci, rows)
                 inf = dm.info()
-                x = np.random.default_rng(1).standard_normal(inf["cols"] + 2)
+                x = np.random.default_rng(1).standard_normal(inf["cols"] + 2).astype(dtype)
                 dx = be.malloc(x.nbytes)
                 dy = be.malloc(rows * 8 + 16)
                 be.h2d(dx, x)
@@ -74,17 +75,17 @@ def main():
         k = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(start, lens)
         ci = ((np.repeat(np.arange(rows, dtype=np.int64), lens) + k) % rows + 1).astype(np.int32)
         rs = np.concatenate(([1], 1 + np.cumsum(lens))).astype(np.int32)
-        extra.append(("banded %dx%d" % (rows, mean), rs, ci, rng.standard_normal(ci.size)))
+        extra.append(("banded %dx%d" % (rows, mean), rs, ci, rng.standard_normal(ci.size).astype(dtype)))
     for rows, scale in ((40000, 30.0), (300000, 8.0)):
         lens = np.minimum((rng.pareto(1.3, rows) * scale).astype(np.int64), rows // 2)
-        extra.append(("pareto %d" % rows,) + matgen.csr_from_lengths(rng, [int(v) for v in lens], rows, np.float64))
+        extra.append(("pareto %d" % rows,) + matgen.csr_from_lengths(rng, [int(v) for v in lens], rows, dtype))
     for sc in (15, 17, 19):
-        extra.append(("rmat%d" % sc,) + matgen.rmat_graph(20, sc, 16, np.float64, values="normal"))
+        extra.append(("rmat%d" % sc,) + matgen.rmat_graph(20, sc, 16, dtype, values="normal"))
     for name, rs, ci, a in extra:
         rows = rs.size - 1
         dm = be.matrix(a, rs, ci, rows)
         inf = dm.info()
-        x = np.random.default_rng(1).standard_normal(inf["cols"] + 2)
+        x = np.random.default_rng(1).standard_normal(inf["cols"] + 2).astype(dtype)
         dx = be.malloc(x.nbytes)
         dy = be.malloc(rows * 8 + 16)
         be.h2d(dx, x)
