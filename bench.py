@@ -246,6 +246,29 @@ def main():
                     "host sees two norms per outer iteration",
         }
 
+    if rank == 0 and n_gpus == 1 and not args.no_npb:
+        # the FP32 twin of the ABI (f_spmv_harness_, what parboil calls) on the same matrix: reported beside the
+        # FP64 headline, never instead of it
+        a32 = m.a.astype(np.float32)
+        dm32 = be.matrix(a32, m.rowstr, m.colidx, m.rows, device=device, cols_hint=m.na)
+        inf32 = dm32.info()
+        x32 = x.astype(np.float32)
+        dx32 = be.malloc(x32.nbytes, device)
+        dy32 = be.malloc(max(m.rows, 1) * 4 + 16, device)
+        be.h2d(dx32, x32, device)
+        dm32.time_device(dx32, dy32, 10)
+        ms32 = dm32.time_device(dx32, dy32, 50) / 50
+        line["spmv_f32"] = {
+            "value": round(2.0 * m.nnz / (ms32 * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "us_per_spmv": round(ms32 * 1e3, 3),
+            "plan": pkg.abi.PLAN_NAMES[inf32["plan"]], "algorithmic_bytes_per_launch": inf32["algorithmic_bytes"],
+            "roofline_frac": round(inf32["algorithmic_bytes"] / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "FP32 values + 16-bit columns are 6 B per nonzero (217 MB for class C): less than the 256-MB Infinity "
+                    "Cache, so a repeated product is partly cache-resident",
+        }
+        dm32.close()
+        be.free(dx32, device)
+        be.free(dy32, device)
+
     if rank == 0 and n_gpus == 1 and cls == "C" and not args.no_scale_ref:
         # the workload of the N > 1 runs (class D, BASELINE configs[4]) on this one GPU, whole matrix:
         # the like-for-like 1-GPU point for the strong-scaling series (the headline above stays class C)
