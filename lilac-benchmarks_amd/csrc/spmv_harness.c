@@ -647,9 +647,21 @@ static int has_static_storage(const void *p, size_t bytes)
  */
 #define DIRECT_PAGEABLE_MIN_BYTES ((size_t)1 << 20)
 
+/* already pinned by an earlier call?  (checked before dladdr(), which walks the link map) */
+static int is_registered(const void *p, size_t bytes)
+{
+    const char *lo = (const char *)p, *hi = lo + bytes;
+    for (int r = 0; r < G.nreg; ++r)
+        if (lo >= G.reg[r].lo && hi <= G.reg[r].hi)
+            return 1;
+    return 0;
+}
+
 static int use_in_place(const void *p, size_t bytes)
 {
     if (G.pin == PIN_PAGEABLE)
+        return 1;
+    if (G.pin != PIN_STAGING && is_registered(p, bytes))
         return 1;
     if (G.pin == PIN_REGISTER || (G.pin == PIN_AUTO && has_static_storage(p, bytes)))
         return ensure_registered(p, bytes);
@@ -661,6 +673,8 @@ static int use_in_place(const void *p, size_t bytes)
 /* Is [p, p+bytes) pinned where it lies (static storage under auto, anything under register)? */
 static int pinned_in_place(const void *p, size_t bytes)
 {
+    if (G.pin != PIN_STAGING && G.pin != PIN_PAGEABLE && is_registered(p, bytes))
+        return 1;
     if (G.pin == PIN_REGISTER || (G.pin == PIN_AUTO && has_static_storage(p, bytes)))
         return ensure_registered(p, bytes);
     return 0;
