@@ -212,7 +212,9 @@ int spmv_hip_synchronize(int device)
 void *spmvd_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    HIPCHK(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), return nullptr);
+    /* portable: pinned for every GPU of the process (SPMV_HIP_DEVICES > 1 copies x from the same buffer to all
+     * of them); mapped: the zero-copy path of the harness reads / writes it from kernels */
+    HIPCHK(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable | hipHostMallocMapped), return nullptr);
     return p;
 }
 
@@ -224,7 +226,7 @@ void spmvd_host_free(void *p)
 
 int spmvd_host_register(void *p, size_t bytes)
 {
-    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault), return -1);
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped), return -1);
     return 0;
 }
 
