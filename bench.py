@@ -318,6 +318,23 @@ def main():
             "npb_mops": round(res["mops"], 2),
             "ms_per_spmv": round(res["t_spmv"] / timed_calls * 1e3, 3),
         }
+        # context only (optional): the same loop row-parallel on this box's CPU share -- same bits,
+        # labelled separately from the faithful single-core baseline above
+        share = min(16, os.cpu_count() or 1)
+        port = orc.Oracle()
+        ymt = np.empty(m.rows)
+        port.spmv_mt(m.a, x[: m.na].copy(), m.rowstr, m.colidx, m.rows, share, out=ymt)  # warm
+        reps_mt = 40
+        t0 = time.perf_counter()
+        for _ in range(reps_mt):
+            _, used = port.spmv_mt(m.a, x[: m.na], m.rowstr, m.colidx, m.rows, share, out=ymt)
+        t_mt = (time.perf_counter() - t0) / reps_mt
+        line["cpu_baseline_threads"] = {
+            "value": round(2.0 * m.nnz / t_mt / 1e9, 3), "unit": "GFLOP/s", "cores": int(used), "kind": "port",
+            "ms_per_spmv": round(t_mt * 1e3, 3),
+            "sample": "%d products of the same matrix with oracle/spmv_oracle_mt.c: native-impl.c's loop on %d threads, "
+                      "rows split by nonzeros (bit-identical to the single-core result)" % (reps_mt, int(used)),
+        }
 
     dm.close()
     be.free(dx, device)

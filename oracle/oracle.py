@@ -57,6 +57,8 @@ class Oracle(_Harness):
             build()
         super().__init__(ORACLE_SO, "spmv_harness_", "f_spmv_harness_")
         L = self.lib
+        L.oracle_spmv_mt.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int]
+        L.oracle_spmv_mt.restype = ctypes.c_int
         L.oracle_spmv_absum.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int]
         L.oracle_spmv_absum.restype = None
         L.oracle_f_spmv_absum.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int]
@@ -87,6 +89,15 @@ class Oracle(_Harness):
         if nnz < 0:
             raise RuntimeError("npb_oracle_makea failed: %d" % nnz)
         return rs, col[:nnz].copy(), a[:nnz].copy()
+
+
+    def spmv_mt(self, a, x, rowstr, colidx, rows, nthreads, out=None):
+        """The same loop on `nthreads` host threads, rows split by nonzeros: bit-identical to spmv() (each row is
+        still summed left to right by one thread).  FP64 only; context for bench.py."""
+        assert a.dtype == np.float64 and x.dtype == np.float64
+        y = np.empty(rows, np.float64) if out is None else out
+        used = self.lib.oracle_spmv_mt(_ptr(y), _ptr(a), _ptr(x), _ptr(rowstr), _ptr(colidx), int(rows), int(nthreads))
+        return y, used
 
 
 class Reference(_Harness):

@@ -83,3 +83,16 @@ def test_absum_bound_helper(oracle):
     ab = oracle.absum(a, x, rs, ci, 100)
     y = oracle.spmv(a, x, rs, ci, 100)
     assert np.all(np.abs(y) <= ab * (1 + 1e-12) + 1e-300)
+
+
+def test_threaded_oracle_is_bit_identical_to_the_sequential_one(oracle):
+    """oracle/spmv_oracle_mt.c (bench.py's all-cores context line): rows split over threads, each row still summed
+    left to right by one thread."""
+    rs, ci, a = matgen.random_csr(91, 7000, 5000, 25, empty_frac=0.1, sort_cols=False, distinct=False)
+    x = np.random.default_rng(91).standard_normal(5000)
+    y0 = oracle.spmv(a, x, rs, ci, 7000)
+    for nt in (1, 2, 7, 16, 300):
+        y, used = oracle.spmv_mt(a, x, rs, ci, 7000, nt)
+        assert 1 <= used <= 256 and np.array_equal(y.view(np.uint64), y0.view(np.uint64))
+    y, used = oracle.spmv_mt(a, x, rs, ci, 3, 8)  # fewer rows than threads
+    assert used == 3 and np.array_equal(y[:3].view(np.uint64), y0[:3].view(np.uint64))
