@@ -644,6 +644,16 @@ static int has_static_storage(const void *p, size_t bytes)
  * megabyte or more is handed to the runtime as it is (its pageable path pins the pages for the
  * duration of the copy and moves 39 MB in 0.9 ms, where memcpy into our staging buffer plus the DMA
  * takes 2.3 ms); below that the fixed cost of the pageable path loses to the staging buffer.
+ *
+ * The pageable path is what the reference does for every vector (cudaMemcpy on the caller's memory,
+ * libspmv/gpu.c:264,285) and it is the right default for solvers, whose work vectors live as long as
+ * the solve: SparseBench 170^3 0.55 s against 1.1 s through staging, 100^3 0.22 against 0.33,
+ * PageRank 0.20 against 0.30.  It is the wrong one for a caller that allocates a fresh vector for
+ * every call: the runtime then pins new pages each time (8 MB: 4-27 ms instead of 0.2), which makes
+ * our BFS driver -- like bfs.cc it creates a new frontier per level -- take 0.43 s instead of 0.23 s
+ * (SPMV_HIP_PIN=staging).  Timing the direct path at run time and falling back was tried and dropped
+ * (profiles/r01_abi_transfer_modes.log): one slow sample costs as much as forty staged calls, a
+ * one-megabyte trial does not show the effect, and two samples are not enough to tell the cases apart.
  */
 #define DIRECT_PAGEABLE_MIN_BYTES ((size_t)1 << 20)
 
