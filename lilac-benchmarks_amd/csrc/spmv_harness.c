@@ -650,8 +650,8 @@ static int has_static_storage(const void *p, size_t bytes)
  * the solve: SparseBench 170^3 0.55 s against 1.1 s through staging, 100^3 0.22 against 0.33,
  * PageRank 0.20 against 0.30.  It is the wrong one for a caller that allocates a fresh vector for
  * every call: the runtime then pins new pages each time (8 MB: 4-27 ms instead of 0.2), which makes
- * our BFS driver -- like bfs.cc it creates a new frontier per level -- take 0.43 s instead of 0.23 s
- * (SPMV_HIP_PIN=staging).  Timing the direct path at run time and falling back was tried and dropped
+ * our BFS driver -- like bfs.cc it creates new vectors as it goes -- take 0.30 s instead of 0.23 s
+ * (SPMV_HIP_PIN=staging; 0.43 s before untouched memory was recognised with mincore(), see mostly_resident).  Timing the direct path at run time and falling back was tried and dropped
  * (profiles/r01_abi_transfer_modes.log): one slow sample costs as much as forty staged calls, a
  * one-megabyte trial does not show the effect, and two samples are not enough to tell the cases apart.
  */
@@ -667,6 +667,34 @@ static int is_registered(const void *p, size_t bytes)
     return 0;
 }
 
+/*
+ * Untouched memory (a calloc'ed vector nobody has written yet: the BFS driver's frontier at the first
+ * level of every source) has no pages behind it; the runtime's pageable path would have to fault every one
+ * of them in while pinning -- 27 ms for 8 MB -- whereas memcpy into the staging buffer reads the shared zero
+ * page.  mincore() tells: one system call per large vector (about 20 us).
+ */
+static int mostly_resident(const void *p, size_t bytes)
+{
+    static unsigned char *vec;
+    static size_t vec_n;
+    const uintptr_t pg = (uintptr_t)G.page;
+    const uintptr_t lo = (uintptr_t)p / pg * pg, hi = ((uintptr_t)p + bytes + pg - 1) / pg * pg;
+    const size_t n = (size_t)((hi - lo) / pg);
+    if (n > vec_n) {
+        free(vec);
+        vec = (unsigned char *)malloc(n);
+        vec_n = vec ? n : 0;
+        if (!vec)
+            return 1;
+    }
+    if (mincore((void *)lo, (size_t)(hi - lo), vec) != 0)
+        return 1; /* cannot tell: behave like the reference */
+    size_t in = 0;
+    for (size_t i = 0; i < n; ++i)
+        in += vec[i] & 1u;
+    return in * 16 >= n * 15;
+}
+
 static int use_in_place(const void *p, size_t bytes)
 {
     if (G.pin == PIN_PAGEABLE)
@@ -676,7 +704,7 @@ static int use_in_place(const void *p, size_t bytes)
     if (G.pin == PIN_REGISTER || (G.pin == PIN_AUTO && has_static_storage(p, bytes)))
         return ensure_registered(p, bytes);
     if (G.pin == PIN_AUTO && bytes >= DIRECT_PAGEABLE_MIN_BYTES)
-        return 1;
+        return mostly_resident(p, bytes);
     return 0;
 }
 
