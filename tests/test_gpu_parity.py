@@ -707,3 +707,28 @@ def test_bench_line_has_the_contract_keys():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-3
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["cores"] == 1
     assert d["npb_cg"]["verified"] and d["npb_cg_device"]["verified"]
+
+
+def test_class_c_full_size_fp32(pkg, backend, oracle):
+    """The FP32 twin (f_spmv_harness_'s kernels) on the full class C pattern: ORDERED and TILED bit-identical to
+    the oracle's float loop, every other plan inside the reordering bound."""
+    m = pkg.npb.NpbMatrix("C")
+    a = m.a.astype(np.float32)
+    x = np.random.default_rng(4).standard_normal(m.na).astype(np.float32)
+    y_ref = oracle.spmv(a, x, m.rowstr, m.colidx, m.rows)
+    absum = oracle.absum(a, x, m.rowstr, m.colidx, m.rows)
+    lens = np.diff(m.rowstr)
+    dm = backend.matrix(a, m.rowstr, m.colidx, m.rows)
+    try:
+        for plan in (pkg.PLAN_AUTO, pkg.PLAN_STRIPED, pkg.PLAN_LANES, pkg.PLAN_TILED, pkg.PLAN_STREAM, pkg.PLAN_ORDERED):
+            dm.set_plan(plan, 0)
+            y = dm.spmv_host(x)
+            if plan in (pkg.PLAN_TILED, pkg.PLAN_ORDERED):
+                assert np.array_equal(bits(y), bits(y_ref)), plan
+            else:
+                assert_close_rows(y, y_ref, absum, lens, np.float32, "class C fp32 plan %d" % plan)
+        y_abi = np.empty(m.rows, np.float32)
+        backend.harness(y_abi, a, x, m.rowstr, m.colidx, m.rows)
+        assert_close_rows(y_abi, y_ref, absum, lens, np.float32, "class C fp32 through the ABI")
+    finally:
+        dm.close()
