@@ -732,3 +732,33 @@ def test_class_c_full_size_fp32(pkg, backend, oracle):
         assert_close_rows(y_abi, y_ref, absum, lens, np.float32, "class C fp32 through the ABI")
     finally:
         dm.close()
+
+
+def test_two_caller_threads(backend, oracle):
+    """The ABI has no handle: callers on different threads share the cache slots behind one lock
+    (libspmv/gpu.c is not thread-safe at all).  Two threads, two matrices, interleaved calls."""
+    import threading
+    mats = [matgen.random_csr(201, 4000, 3000, 20), matgen.random_csr(202, 2500, 5000, 35)]
+    xs = [np.random.default_rng(i).standard_normal(n) for i, n in ((1, 3000), (2, 5000))]
+    refs = [oracle.spmv(a, x, rs, ci, rs.size - 1) for (rs, ci, a), x in zip(mats, xs)]
+    absums = [oracle.absum(a, x, rs, ci, rs.size - 1) for (rs, ci, a), x in zip(mats, xs)]
+    errors = []
+
+    def work(k):
+        rs, ci, a = mats[k]
+        y = np.empty(rs.size - 1)
+        for _ in range(60):
+            backend.harness(y, a, xs[k], rs, ci, rs.size - 1)
+            try:
+                assert_close_rows(y, refs[k], absums[k], np.diff(rs), np.float64, "thread %d" % k)
+            except AssertionError as e:  # pragma: no cover
+                errors.append(str(e))
+                return
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[0]
+    assert backend.stats()["uploads"] <= 4  # both matrices stayed cached
