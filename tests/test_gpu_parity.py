@@ -762,3 +762,15 @@ def test_two_caller_threads(backend, oracle):
         t.join()
     assert not errors, errors[0]
     assert backend.stats()["uploads"] <= 4  # both matrices stayed cached
+
+
+def test_the_references_own_plugin_test_accepts_the_library(pkg, tmp_path):
+    """libspmv/test.cpp compiled from the reference's source (oracle/_ref/spmv_test, built where the reference is
+    present): it dlopens ./<name>.so, needs both symbols, runs its known-answer product and prints success!."""
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "spmv_test")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/spmv_test was not built (no reference checkout at build time)")
+    import shutil
+    shutil.copy(pkg.lib_path(), str(tmp_path / "hip.so"))
+    r = subprocess.run([exe, "hip"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "success!" in r.stderr, r.stderr
