@@ -8,6 +8,7 @@ Bars (BASELINE.json north_star):
   * NPB CG: zeta within 1e-10 relative of the verification value (cg.f:363-368).
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -774,3 +775,21 @@ def test_the_references_own_plugin_test_accepts_the_library(pkg, tmp_path):
     shutil.copy(pkg.lib_path(), str(tmp_path / "hip.so"))
     r = subprocess.run([exe, "hip"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 0 and "success!" in r.stderr, r.stderr
+
+
+def test_the_references_bfs_program_runs_on_the_library():
+    """bfs/bfs.cc + bfs/library.cc compiled from the reference's source with its makefile's recipe and LINKED against
+    libhip-spmv.so (oracle/_ref/bfs_hip): the real caller, unchanged, on the new backend.  It reads the bundled
+    input.mtx from stdin, runs 16 BFS from random sources and prints the elapsed seconds (bfs.cc:70-95); the
+    library's statistics show the products it asked for."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "bfs_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/bfs_hip was not built (no reference checkout at build time)")
+    with open(os.path.join(GOLD, "bfs", "input.mtx")) as f:
+        r = subprocess.run([exe], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                           env=dict(os.environ, SPMV_HIP_STATS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert float(r.stdout.strip().splitlines()[-1]) > 0.0
+    m = re.search(r"libhip-spmv: calls=(\d+) uploads=(\d+)", r.stderr)
+    assert m and int(m.group(1)) >= 16 and int(m.group(2)) == 1, r.stderr[-500:]
