@@ -167,3 +167,30 @@ def test_matrix_market_samples_of_the_reference_converter(pkg, oracle, name, sha
     yf = oracle.spmv(af.copy(), x.astype(np.float32), rsf.copy(), cif.copy(), mf.rows)
     assert np.allclose(yf, mirrored @ x, rtol=2e-5, atol=2e-4)
     C.free(mf)
+
+
+def _run_parboil(exe, dataset, mtx, tmp_path):
+    import subprocess
+    d = os.path.join(GOLD, dataset)
+    out = str(tmp_path / (mtx + ".out"))
+    r = subprocess.run([exe, "-i", os.path.join(d, mtx) + "," + os.path.join(d, "vector.bin"), "-o", out],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and "Compute" in r.stdout, r.stdout + r.stderr
+    return out, os.path.join(d, mtx + ".out")
+
+
+@pytest.mark.parametrize("dataset,mtx", [("parboil_small", "1138_bus.mtx"), ("parboil_medium", "bcsstk18.mtx")])
+def test_the_references_parboil_program_on_the_oracle(pkg, tmp_path, dataset, mtx):
+    """parboil's spmv cpu caller compiled from the reference's sources (oracle/_ref/parboil_spmv_oracle: main.c,
+    file.c, the converter, mmio.c, parboil.c) and linked against liboracle-spmv.so: the real caller, the real file
+    I/O, our restatement of the arithmetic.  `small` comes out byte-identical to the shipped .out file; `medium`
+    passes the reference's comparator."""
+    exe = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "parboil_spmv_oracle")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/parboil_spmv_oracle was not built (no reference checkout at build time)")
+    out, gold = _run_parboil(os.path.abspath(exe), dataset, mtx, tmp_path)
+    a, b = np.fromfile(out, np.uint8), np.fromfile(gold, np.uint8)
+    assert a.size == b.size and np.array_equal(a[:4], b[:4])
+    if dataset == "parboil_small":
+        assert np.array_equal(a, b)
+    assert pkg.callers.pb_compare(b[4:].view(np.float32), a[4:].view(np.float32)) == 0

@@ -793,3 +793,24 @@ def test_the_references_bfs_program_runs_on_the_library():
     assert float(r.stdout.strip().splitlines()[-1]) > 0.0
     m = re.search(r"libhip-spmv: calls=(\d+) uploads=(\d+)", r.stderr)
     assert m and int(m.group(1)) >= 16 and int(m.group(2)) == 1, r.stderr[-500:]
+
+
+@pytest.mark.parametrize("dataset,mtx", [("parboil_small", "1138_bus.mtx"), ("parboil_medium", "bcsstk18.mtx")])
+def test_the_references_parboil_program_runs_on_the_library(pkg, tmp_path, dataset, mtx):
+    """The same reference program linked against libhip-spmv.so (oracle/_ref/parboil_spmv_hip): 50 calls of
+    f_spmv_harness_ on the GPU, output file judged by the reference's comparator against the shipped .out."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "parboil_spmv_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/parboil_spmv_hip was not built (no reference checkout at build time)")
+    d = os.path.join(GOLD, dataset)
+    out = str(tmp_path / "out.bin")
+    r = subprocess.run([exe, "-i", os.path.join(d, mtx) + "," + os.path.join(d, "vector.bin"), "-o", out],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=str(tmp_path),
+                       env=dict(os.environ, SPMV_HIP_STATS="1"))
+    assert r.returncode == 0 and "Compute" in r.stdout, r.stdout + r.stderr
+    a = np.fromfile(out, np.uint8)
+    b = np.fromfile(os.path.join(d, mtx + ".out"), np.uint8)
+    assert a.size == b.size and np.array_equal(a[:4], b[:4])
+    assert pkg.callers.pb_compare(b[4:].view(np.float32), a[4:].view(np.float32)) == 0
+    assert "libhip-spmv: calls=50 uploads=1" in r.stderr
