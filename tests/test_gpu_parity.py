@@ -744,6 +744,7 @@ def test_two_caller_threads(backend, oracle):
     refs = [oracle.spmv(a, x, rs, ci, rs.size - 1) for (rs, ci, a), x in zip(mats, xs)]
     absums = [oracle.absum(a, x, rs, ci, rs.size - 1) for (rs, ci, a), x in zip(mats, xs)]
     errors = []
+    backend.reset_stats()
 
     def work(k):
         rs, ci, a = mats[k]
