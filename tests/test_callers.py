@@ -194,3 +194,15 @@ def test_the_references_parboil_program_on_the_oracle(pkg, tmp_path, dataset, mt
     if dataset == "parboil_small":
         assert np.array_equal(a, b)
     assert pkg.callers.pb_compare(b[4:].view(np.float32), a[4:].view(np.float32)) == 0
+
+
+def test_the_references_bfs_program_on_the_oracle():
+    """bfs/bfs.cc + bfs/library.cc from the reference's source, linked against liboracle-spmv.so
+    (oracle/_ref/bfs_oracle): reads the bundled input.mtx from stdin, runs its 16 BFS, prints its elapsed seconds."""
+    import subprocess
+    exe = os.path.abspath(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "bfs_oracle"))
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/bfs_oracle was not built (no reference checkout at build time)")
+    with open(os.path.join(GOLD, "bfs", "input.mtx")) as f:
+        r = subprocess.run([exe], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and float(r.stdout.strip().splitlines()[-1]) >= 0.0, r.stderr
