@@ -190,7 +190,58 @@ static void guard_unprotect(guard *g)
         mprotect(g->lo, (size_t)(g->hi - g->lo), PROT_READ | PROT_WRITE);
 }
 
-/* async-signal-safe: only mprotect and stores to sig_atomic_t */
+/* Do two slots protect a common page? */
+static int guards_share_pages(const slot *a, const slot *b)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            if (a->g[i].hi > a->g[i].lo && b->g[j].hi > b->g[j].lo && a->g[i].lo < b->g[j].hi &&
+                b->g[j].lo < a->g[i].hi)
+                return 1;
+    return 0;
+}
+
+/*
+ * Takes the page protection off `first` and marks it dirty.  Cached matrices may share host pages
+ * (spmv_harness_ and f_spmv_harness_ on one rowstr/colidx, two matrices with one sparsity pattern, the
+ * same arrays with another `rows`): making `first`'s pages writable again silently takes the write
+ * detection away from every other armed slot that guards one of them, so those are marked dirty too
+ * (they upload again at their next call and re-arm), and so on until nothing armed overlaps anything
+ * disarmed.  Async-signal-safe: mprotect, pointer compares and plain stores only.
+ */
+static void disarm_cascade(slot *first)
+{
+    first->dirty = 1;
+    first->armed = 0;
+    for (int changed = 1; changed;) {
+        changed = 0;
+        for (int t = 0; t < MAX_SLOTS; ++t) {
+            slot *st = &G.slots[t];
+            if (!st->armed)
+                continue;
+            for (int u = 0; u < MAX_SLOTS; ++u) {
+                const slot *su = &G.slots[u];
+                if (su != st && su->used && !su->armed && su->dirty && guards_share_pages(st, su)) {
+                    st->dirty = 1;
+                    st->armed = 0;
+                    changed = 1;
+                    break;
+                }
+            }
+        }
+    }
+    for (int t = 0; t < MAX_SLOTS; ++t) {
+        slot *st = &G.slots[t];
+        if (!st->used || st->armed || !st->dirty)
+            continue;
+        for (int k = 0; k < 3; ++k) {
+            guard_unprotect(&st->g[k]);
+            st->g[k].hi = st->g[k].lo; /* nothing protected any more: later cascades must not see it */
+        }
+    }
+}
+
+/* async-signal-safe: only mprotect and stores to sig_atomic_t / slot fields */
 static void on_segv(int sig, siginfo_t *si, void *ctx)
 {
     char *addr = (char *)si->si_addr;
@@ -200,12 +251,9 @@ static void on_segv(int sig, siginfo_t *si, void *ctx)
             continue;
         for (int k = 0; k < 3; ++k) {
             if (addr >= sl->g[k].lo && addr < sl->g[k].hi) {
-                /* the caller is editing a cached matrix: let the write through
-                 * and drop the device copy at the next call (gpu.c:162-183) */
-                sl->dirty = 1;
-                sl->armed = 0;
-                for (int j = 0; j < 3; ++j)
-                    guard_unprotect(&sl->g[j]);
+                /* the caller is editing a cached matrix: let the write through and drop the device
+                 * copy at the next call (gpu.c:162-183) -- of every slot that guards these pages */
+                disarm_cascade(sl);
                 return;
             }
         }
@@ -316,11 +364,8 @@ static void slot_drop(slot *sl)
 {
     if (!sl->used)
         return;
-    if (sl->armed) {
-        sl->armed = 0;
-        for (int k = 0; k < 3; ++k)
-            guard_unprotect(&sl->g[k]);
-    }
+    if (sl->armed)
+        disarm_cascade(sl); /* slots that share its pages lose their protection with it: they re-upload */
     for (int k = 0; k < 3; ++k)
         guard_free(&sl->g[k]);
     for (int p = 0; p < sl->nparts; ++p) {
@@ -567,10 +612,7 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
             if (G.verbose)
                 fprintf(stderr, "libhip-spmv: mprotect failed (%s); matrix will not be cached\n",
                         strerror(errno));
-            sl->armed = 0;
-            for (int k = 0; k < 3; ++k)
-                guard_unprotect(&sl->g[k]);
-            sl->dirty = 1;
+            disarm_cascade(sl);
         }
     }
     G.st.uploads++;

@@ -326,7 +326,8 @@ int bfs_read_pairs(const char *path, csr_d *out)
     if (!f)
         return -1;
     long rows, cols, n;
-    if (fscanf(f, "%ld %ld %ld", &rows, &cols, &n) != 3 || rows <= 0 || n < 0) {
+    if (fscanf(f, "%ld %ld %ld", &rows, &cols, &n) != 3 || rows <= 0 || cols <= 0 || n < 0 || rows > 0x7ffffff0L ||
+        cols > 0x7ffffff0L || n > 0x7ffffff0L) {
         fclose(f);
         return -2;
     }
@@ -337,8 +338,8 @@ int bfs_read_pairs(const char *path, csr_d *out)
         return -3;
     }
     for (long i = 0; i < n; ++i)
-        if (fscanf(f, "%d %d", &x[i], &y[i]) != 2) {
-            fclose(f);
+        if (fscanf(f, "%d %d", &x[i], &y[i]) != 2 || x[i] < 0 || x[i] > rows || y[i] < 0 || y[i] > cols) {
+            fclose(f); /* truncated, or an index outside the shape (library.cc:169-184 trusts the file) */
             free(x), free(y);
             return -2;
         }
@@ -453,6 +454,8 @@ static int mm_header(FILE *f, mm_info *h)
     } while (line[0] == '%');
     if (sscanf(line, "%d %d %ld", &h->rows, &h->cols, &h->nz) != 3)
         return -2;
+    if (h->rows <= 0 || h->cols <= 0 || h->nz < 0 || h->nz > 0x3fffffffL)
+        return -2; /* the reference converter trusts the file; a driver handed to maintainers must not */
     return 0;
 }
 
@@ -489,6 +492,13 @@ int pb_coo_to_csr(const char *mtx_path, int mirrored, int binary, csr_f *out)
         }
         e[cur].row--;
         e[cur].col--;
+        /* an index outside the announced shape would be written outside rowstr[] below (mirrored: both ways) */
+        if (e[cur].row < 0 || e[cur].row >= h.rows || e[cur].col < 0 || e[cur].col >= h.cols ||
+            (mirrored && (e[cur].col >= h.rows || e[cur].row >= h.cols))) {
+            fclose(f);
+            free(e);
+            return -2;
+        }
         if (mirrored && e[cur].row != e[cur].col) {
             ++cur;
             e[cur].val = e[cur - 1].val;
@@ -633,6 +643,11 @@ int mm_read_csr(const char *path, csr_d *out)
         double v = 1.0;
         if (h.pattern ? fscanf(f, "%d %d", &r, &c) != 2 : fscanf(f, "%d %d %lf", &r, &c, &v) != 3)
             break;
+        if (r < 1 || r > h.rows || c < 1 || c > h.cols || (h.symmetric && (c > h.rows || r > h.cols))) {
+            fclose(f);
+            free(ri), free(ci), free(va);
+            return -2; /* malformed file: indices outside the announced shape */
+        }
         ri[cur] = r - 1, ci[cur] = c - 1, va[cur] = v, ++cur;
         if (h.symmetric && r != c)
             ri[cur] = c - 1, ci[cur] = r - 1, va[cur] = v, ++cur;

@@ -22,6 +22,34 @@ def pkg():
     return p
 
 
+def build_planlib():
+    """The host-side planners and layout builders (plain C, csrc/spmv_plan.c and friends) as a test-only
+    shared library: libhip-spmv.so exports only the ABI and the documented spmv_hip_* API (csrc/libhip-spmv.map),
+    so the tests that walk the layouts on the CPU compile these sources themselves."""
+    import subprocess
+    csrc = os.path.join(ROOT, "lilac-benchmarks_amd", "csrc")
+    out_dir = os.path.join(ROOT, "tests", "native", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libspmvplan.so")
+    srcs = [os.path.join(csrc, f) for f in PLAN_SOURCES]
+    deps = srcs + [os.path.join(csrc, "spmv_internal.h"), os.path.join(ROOT, "include", "spmv_hip.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        tmp = out + ".%d.tmp" % os.getpid()
+        subprocess.run(["gcc", "-std=c11", "-O2", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + csrc]
+                       + srcs + ["-lm", "-lpthread", "-o", tmp], check=True)
+        os.replace(tmp, out)
+    return out
+
+
+PLAN_SOURCES = ("spmv_plan.c", "spmv_striped.c", "spmv_lanes.c", "spmv_tiled.c")
+
+
+@pytest.fixture(scope="session")
+def planlib():
+    import ctypes
+    return ctypes.CDLL(build_planlib())
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle.oracle import Oracle

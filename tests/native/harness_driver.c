@@ -158,6 +158,69 @@ int main(int argc, char **argv)
         printf("ok float twin (%s)\n", policy);
     }
 
+    /* Cached matrices that share protected host pages: a double and a float matrix on ONE rowstr / colidx
+     * (>= 64 whole pages each, so they are page-protected under the default policy).  A write into the
+     * shared colidx must refresh BOTH device copies; evicting one slot must not leave the other one
+     * unguarded; the same arrays with another `rows` are a third slot over the same pages. */
+    if (strcmp(policy, "pointer")) {
+        const int n = 100000, len = 4;
+        int *rs = (int *)malloc(((size_t)n + 1) * sizeof(int)), *ci = (int *)malloc((size_t)n * len * sizeof(int));
+        double *da = (double *)malloc((size_t)n * len * sizeof(double));
+        float *fa = (float *)malloc((size_t)n * len * sizeof(float));
+        double *dx = (double *)malloc((size_t)n * sizeof(double)), *dy = (double *)malloc((size_t)n * sizeof(double));
+        float *fx = (float *)malloc((size_t)n * sizeof(float)), *fy = (float *)malloc((size_t)n * sizeof(float));
+        for (int r = 0; r <= n; ++r)
+            rs[r] = 1 + len * r;
+        for (int j = 0; j < n * len; ++j) {
+            ci[j] = 1 + (int)(((int64_t)j * 7919) % n);
+            da[j] = rnd();
+            fa[j] = (float)rnd();
+        }
+        ci[n * len - 1] = n;
+        for (int i = 0; i < n; ++i)
+            dx[i] = rnd(), fx[i] = (float)rnd();
+        int nn = n;
+        csr dm = {n, n, (int64_t)n * len, rs, ci, da};
+#define CHECK_F()                                                  \
+    for (int r = 0; r < nn; ++r) {                                 \
+        float acc = 0.0f;                                          \
+        for (int j = rs[r] - 1; j < rs[r + 1] - 1; ++j)            \
+            acc += fa[j] * fx[ci[j] - 1];                          \
+        EXPECT(acc == fy[r]);                                      \
+    }
+        spmv_harness_(dy, da, dx, rs, ci, &nn);
+        f_spmv_harness_(fy, fa, fx, rs, ci, &nn);
+        check(&dm, dx, dy);
+        CHECK_F();
+        /* one edit in the middle of the shared colidx: both copies are stale */
+        ci[n * len / 2] = ci[n * len / 2] % (n - 1) + 1;
+        spmv_harness_(dy, da, dx, rs, ci, &nn);
+        check(&dm, dx, dy);
+        f_spmv_harness_(fy, fa, fx, rs, ci, &nn);
+        CHECK_F();
+        /* an edit of the double values only: the float copy's pages (rowstr/colidx) went writable with the
+         * double slot's, so its next call must not trust them -- edit colidx right after, without a fault */
+        da[n] += 1.0;
+        ci[n * len / 3] = ci[n * len / 3] % (n - 1) + 1;
+        f_spmv_harness_(fy, fa, fx, rs, ci, &nn);
+        CHECK_F();
+        spmv_harness_(dy, da, dx, rs, ci, &nn);
+        check(&dm, dx, dy);
+        /* the same arrays with fewer rows: a third slot over the same pages */
+        int fewer2 = n - 7;
+        spmv_harness_(dy, da, dx, rs, ci, &fewer2);
+        ci[5 * len] = ci[5 * len] % (n - 1) + 1;
+        spmv_harness_(dy, da, dx, rs, ci, &fewer2);
+        spmv_harness_(dy, da, dx, rs, ci, &nn);
+        check(&dm, dx, dy);
+        f_spmv_harness_(fy, fa, fx, rs, ci, &nn);
+        CHECK_F();
+#undef CHECK_F
+        spmv_hip_release();
+        free(rs), free(ci), free(da), free(fa), free(dx), free(dy), free(fx), free(fy);
+        printf("ok slots sharing protected pages (%s)\n", policy);
+    }
+
     /* degenerate shapes: no rows, all rows empty */
     {
         int zero = 0, three = 3;

@@ -31,10 +31,23 @@ def test_exports_every_declared_symbol(pkg):
     assert {"spmv_harness_", "f_spmv_harness_"} <= syms  # libspmv/native.c:3,8
 
 
+def test_exports_nothing_but_the_abi_and_the_documented_api(pkg):
+    """The reference's native.so exports its two harness symbols and the two inner functions
+    (libspmv/Makefile:13-14); installed AS libnative-spmv.so under Fortran/C++ callers, this library must not
+    add collision surface: the dynamic symbol table is the ABI plus include/spmv_hip.h, nothing internal
+    (csrc/libhip-spmv.map)."""
+    syms = exported(pkg.lib_path())
+    documented = set(declared_functions("spmv_harness.h")) | set(declared_functions("spmv_hip.h"))
+    assert syms == documented, sorted(syms ^ documented)
+    assert all(s in ("spmv_harness_", "f_spmv_harness_") or s.startswith("spmv_hip_") for s in syms)
+
+
 def test_library_is_self_contained_for_callers(pkg):
     dyn = subprocess.run(["readelf", "-d", pkg.lib_path()], stdout=subprocess.PIPE, text=True, check=True).stdout
     assert "libamdhip64" in dyn  # DT_NEEDED: a bare -lhip-spmv links (SURVEY 8(b) packaging)
     assert "SONAME" not in dyn  # like the reference's .so files (libspmv/Makefile:14)
+    paths = re.findall(r"(?:RUNPATH|RPATH).*\[(.*)\]", dyn)
+    assert len(paths) == 1 and ":" not in paths[0], paths  # one entry, from $(RPATH) of csrc/Makefile, not hipcc's own
 
 
 def test_loads_and_reports_no_device_without_aborting(pkg):

@@ -206,3 +206,27 @@ def test_the_references_bfs_program_on_the_oracle():
     with open(os.path.join(GOLD, "bfs", "input.mtx")) as f:
         r = subprocess.run([exe], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 0 and float(r.stdout.strip().splitlines()[-1]) >= 0.0, r.stderr
+
+
+@pytest.mark.parametrize("reader,text", [
+    ("mm", "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n0 2 2.0\n"),       # row 0
+    ("mm", "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n4 2 2.0\n"),       # row > rows
+    ("mm", "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n2 -7 2.0\n"),      # negative column
+    ("mm", "%%MatrixMarket matrix coordinate real symmetric\n2 5 1\n1 4 2.0\n"),              # mirror lands outside
+    ("mm", "%%MatrixMarket matrix coordinate real general\n0 3 0\n"),                         # no rows
+    ("pb", "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n0 2 2.0\n"),
+    ("pb", "%%MatrixMarket matrix coordinate real general\n3 3 1\n9 1 1.0\n"),
+    ("pb", "%%MatrixMarket matrix coordinate real general\n3 3 1\n1 2000000000 1.0\n"),
+    ("bfs", "4 4 2\n1 2\n7 1\n"),                                                             # x > rows
+    ("bfs", "4 4 2\n1 2\n2 -1\n"),                                                            # negative y
+    ("bfs", "4 4 3\n1 2\n2 1\n"),                                                             # truncated
+])
+def test_malformed_files_are_refused_not_indexed(pkg, tmp_path, reader, text):
+    """The reference's converters index by file contents (convert_dataset.c:93-155, library.cc:169-184); ours are
+    handed to maintainers in INTEGRATION.md, so an index outside the announced shape is rc = -2, not a heap write."""
+    C = pkg.callers
+    path = str(tmp_path / "bad.mtx")
+    open(path, "w").write(text)
+    fn = {"mm": C.mm_read, "pb": C.pb_load, "bfs": C.bfs_read}[reader]
+    with pytest.raises(RuntimeError, match="-2"):
+        fn(path)

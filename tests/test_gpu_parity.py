@@ -214,6 +214,51 @@ def test_float_and_double_in_one_process(backend, oracle):
     assert_close_rows(yf, oracle.spmv(af, xf, rs, ci, 3000), oracle.absum(af, xf, rs, ci, 3000), lens, np.float32, "f32")
 
 
+def test_cached_matrices_that_share_protected_pages(backend, oracle):
+    """A double and a float matrix on ONE rowstr/colidx, each array >= 64 whole pages, so page-protected under
+    the default policy (and uploaded from PROT_READ pages by the second matrix); then the same arrays with another
+    `rows`.  A write through the shared pages must refresh every cached copy that guards them -- the first slot's
+    handler used to make the pages writable again and leave the others armed but blind."""
+    rows = 100000
+    rs, ci, a = matgen.random_csr(62, rows, rows, 4, empty_frac=0.0, spread=0.0)
+    assert ci.nbytes >= 65 * 4096 and rs.nbytes >= 65 * 4096
+    rng = np.random.default_rng(62)
+    x = rng.standard_normal(rows)
+    af, xf = a.astype(np.float32), x.astype(np.float32)
+    y, yf = np.empty(rows), np.empty(rows, np.float32)
+    lens = np.diff(rs)
+
+    def check(n=rows):
+        assert_close_rows(y[:n], oracle.spmv(a, x, rs, ci, n), oracle.absum(a, x, rs, ci, n), lens[:n], np.float64, "f64")
+
+    def check_f():
+        assert_close_rows(yf, oracle.spmv(af, xf, rs, ci, rows), oracle.absum(af, xf, rs, ci, rows), lens, np.float32, "f32")
+
+    backend.reset_stats()
+    backend.harness(y, a, x, rs, ci, rows)
+    backend.harness(yf, af, xf, rs, ci, rows)  # uploads rowstr/colidx from pages the first slot made read-only
+    check(), check_f()
+    ci[ci.size // 2] = ci[ci.size // 2] % (rows - 1) + 1  # shared colidx, interior page: both copies are stale
+    backend.harness(y, a, x, rs, ci, rows)
+    backend.harness(yf, af, xf, rs, ci, rows)
+    check(), check_f()
+    assert backend.stats()["uploads"] == 4
+    a[rows] += 1.0  # the double values only ...
+    ci[ci.size // 3] = ci[ci.size // 3] % (rows - 1) + 1  # ... which took the protection off the shared colidx too
+    backend.harness(yf, af, xf, rs, ci, rows)
+    backend.harness(y, a, x, rs, ci, rows)
+    check(), check_f()
+    fewer = rows - 7  # same arrays, other `rows`: a third slot over the same pages
+    backend.harness(y, a, x, rs, ci, fewer)
+    ci[20] = ci[20] % (rows - 1) + 1
+    backend.harness(y, a, x, rs, ci, fewer)
+    check(fewer)
+    backend.harness(y, a, x, rs, ci, rows)
+    backend.harness(yf, af, xf, rs, ci, rows)
+    check(), check_f()
+    backend.release()
+
+
 # ------------------------------------------------------------------ callers
 def bfs(spmv, rs, ci, a, n, source):
     """bfs/bfs.cc:36-68 with the SpMV passed in; returns distances and the frontier of every level."""

@@ -12,8 +12,8 @@ from test_plan import lanes_emulate, striped_emulate, tiled_emulate
 
 
 @pytest.fixture(scope="module")
-def lib(pkg):
-    return pkg.Backend().lib
+def lib(planlib):
+    return planlib
 
 
 @st.composite

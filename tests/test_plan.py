@@ -78,8 +78,8 @@ def check_stream_plan(rowstr, r0, r1, p):
 
 
 @pytest.fixture(scope="module")
-def lib(pkg):
-    return pkg.Backend().lib
+def lib(planlib):
+    return planlib
 
 
 def test_stream_plan_on_edge_cases(lib):
@@ -331,10 +331,10 @@ def test_striped_rejects_hypersparse(lib):
 _LAYOUT_HASH = r"""
 import sys, ctypes, hashlib, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
-import pkgload, matgen
+import matgen
+from conftest import build_planlib
 from test_plan import StripedHost
-pkg = pkgload.load_package()
-lib = ctypes.CDLL(pkg.lib_path())
+lib = ctypes.CDLL(build_planlib())
 rs, ci, a = matgen.random_csr(77, 9000, 40000, 60)
 t = StripedHost()
 lib.spmv_striped_build.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 8 + [ctypes.POINTER(StripedHost)]
