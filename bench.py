@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cls", default=None, help="override the NPB class (default: C at N=1, D at N>1)")
-    ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered|tiled|striped|lanes")
+    ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered|tiled|striped")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-npb", action="store_true", help="skip the full NPB CG run through the ABI")
     ap.add_argument("--cpu-iters", type=int, default=10, help="timed CG iterations of the CPU sample")
@@ -115,7 +115,7 @@ def main():
     if args.plan != "auto":
         name, _, par = args.plan.partition(":")
         plan = {"stream": pkg.PLAN_STREAM, "vector": pkg.PLAN_VECTOR, "binned": pkg.PLAN_BINNED,
-                "ordered": pkg.PLAN_ORDERED, "tiled": pkg.PLAN_TILED, "striped": pkg.PLAN_STRIPED, "lanes": pkg.PLAN_LANES}[name]
+                "ordered": pkg.PLAN_ORDERED, "tiled": pkg.PLAN_TILED, "striped": pkg.PLAN_STRIPED}[name]
         dm.set_plan(plan, int(par) if par else 0)
     info = dm.info()
     x = np.random.default_rng(12345).standard_normal(m.na + 2)  # same on every rank: x is replicated

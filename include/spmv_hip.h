@@ -29,10 +29,9 @@ enum {
     SPMV_HIP_PLAN_TILED = 5,   /* column stripes of x held in LDS, one row per lane; sums each  */
                                /* row stripe by stripe in stored order: bit-identical to the    */
                                /* reference when a row's columns are sorted                     */
-    SPMV_HIP_PLAN_STRIPED = 6, /* 2-D: a workgroup keeps one stripe of x in LDS for its whole    */
-                               /* life; per-(stripe,row) partial sums added in stripe order      */
-    SPMV_HIP_PLAN_LANES = 7    /* the same 2-D decomposition with whole (row,stripe) segments     */
-                               /* dealt to lanes: one FMA per entry, no cross-lane work          */
+    SPMV_HIP_PLAN_STRIPED = 6  /* 2-D: a workgroup = (group of column stripes, row block); one stripe */
+                               /* of x in LDS at a time, row sums carried in registers across the  */
+                               /* group, one partial sum per (group, row), added in group order     */
 };
 
 /* Opaque device-resident matrix (CSR block + execution plan) on one GPU. */
@@ -137,11 +136,10 @@ int spmv_hip_memset(int device, void *dst_dev, int value, size_t bytes);
 int spmv_hip_synchronize(int device);
 
 /* Experiment switches used by tools/kbench.py (not a stable interface; they affect matrices and
- * plans created afterwards): 0 XCD-contiguous block order of k_stream (default 1); 1 non-temporal
+ * plans created afterwards): 0 XCD-contiguous block order of k_stream / k_striped (default 1); 1 non-temporal
  * loads of a/colidx (0); 2-4 TILED geometry (waves per workgroup, LDS bytes per stripe, workgroups
- * aimed for); 5 register sets of k_tiled / k_striped / k_lanes; 7-10 STRIPED / LANES geometry (LDS
- * bytes per stripe 65536|131072, waves per workgroup 8|16, workgroups aimed for, entries per lane
- * per sub-window 4|8). */
+ * aimed for); 5 register sets of k_tiled / k_striped; 9, 11, 12 STRIPED geometry (workgroups aimed
+ * for, stripe groups (0 = choose), most rows per wave range). */
 void spmv_hip_set_tuning(int key, int value);
 
 /* ---- ABI-path control ------------------------------------------------------ */

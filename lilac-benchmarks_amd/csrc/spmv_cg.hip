@@ -9,7 +9,7 @@
  * that does not know them loses nothing.
  *
  * One CG iteration (cg.f:513-620) = SpMV (q = A p) + three vector kernels, no host sync:
- *   k_dot      d_part[b]   = sum over block b of p*q   (folded into k_stripe_sum under the STRIPED plan)
+ *   k_dot      d_part[b]   = sum over block b of p*q   (folded into k_striped under the STRIPED plan)
  *   k_axpy     alpha = rho/d with rho = sum(rho_part_prev), d = sum(d_part) (every block adds the
  *              ~150 partials itself, in index order);  z += alpha p;  r -= alpha q;
  *              rho_part_new[b] = sum over block b of r*r
@@ -248,8 +248,9 @@ spmv_hip_cg *spmv_hip_cg_create(spmv_hip_matrix *m)
     for (double **v : vecs)
         ok = ok && hipMalloc((void **)v, vb) == hipSuccess && hipMemset(*v, 0, vb) == hipSuccess;
     for (int k = 0; k < 4; ++k)
-        ok = ok && hipMalloc((void **)&c->part[k], ((size_t)(c->n + SPMV_WG - 1) / SPMV_WG + 1) * sizeof(double)) ==
-                       hipSuccess; /* room for one partial per 256 rows (the folded dot), nb <= that */
+        ok = ok && hipMalloc((void **)&c->part[k], ((size_t)c->n + 64) * sizeof(double)) ==
+                       hipSuccess; /* room for one partial per wave range of the STRIPED plan (the folded dot: at most
+                                      rows + 16 of them), nb <= that */
     ok = ok && hipHostMalloc((void **)&c->h_part, (size_t)(2 * c->nb + 2) * sizeof(double), hipHostMallocDefault) ==
                    hipSuccess;
     if (!ok) {

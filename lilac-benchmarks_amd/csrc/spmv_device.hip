@@ -111,11 +111,6 @@ struct spmv_hip_matrix {
     bool striped_mostly_filler = false;
     int striped_rc = 0;
     spmv_dev_striped ds{};
-    /* LANES (built on demand) */
-    bool have_lanes = false;
-    bool lanes_mostly_pad = false;
-    int lanes_rc = 0;
-    spmv_dev_lanes dl{};
 };
 
 extern "C" {
@@ -293,21 +288,13 @@ static void free_plans(spmv_hip_matrix *m)
     if (m->d_binrows)
         (void)hipFree(m->d_binrows);
     if (m->have_striped) {
-        (void)hipFree((void *)m->ds.wptr);
-        (void)hipFree((void *)m->ds.wrow);
+        (void)hipFree((void *)m->ds.tptr);
+        (void)hipFree((void *)m->ds.rrow);
         (void)hipFree((void *)m->ds.col);
         (void)hipFree((void *)m->ds.val);
-        (void)hipFree(m->ds.partial);
+        if (m->ds.partial)
+            (void)hipFree(m->ds.partial);
         m->have_striped = false;
-    }
-    if (m->have_lanes) {
-        (void)hipFree((void *)m->dl.wptr);
-        (void)hipFree((void *)m->dl.wslot);
-        (void)hipFree((void *)m->dl.islot);
-        (void)hipFree((void *)m->dl.col);
-        (void)hipFree((void *)m->dl.val);
-        (void)hipFree(m->dl.partial);
-        m->have_lanes = false;
     }
     if (m->have_tiled) {
         (void)hipFree((void *)m->dt.wptr);
@@ -472,9 +459,8 @@ static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_
 static int g_relayout = 1;
 extern "C" void spmvd_set_relayout(int on) { g_relayout = on ? 1 : 0; }
 
-/* geometry knobs of the STRIPED plan (experiments through spmv_hip_set_tuning keys 7..9) */
-static int g_stripe_xbytes = SPMV_STRIPE_XBYTES, g_stripe_wpb = SPMV_STRIPE_WPB, g_stripe_wgs = SPMV_STRIPE_TARGET_WGS,
-           g_stripe_epl = SPMV_STRIPE_EPL;
+/* geometry knobs of the STRIPED plan (experiments through spmv_hip_set_tuning keys 9, 11, 12) */
+static int g_stripe_wgs = SPMV_STRIPE_TARGET_WGS, g_stripe_groups = 0, g_stripe_wave_rows = SPMV_STRIPE_WAVE_ROWS;
 
 /* Builds the STRIPED layout; same conventions as ensure_tiled. */
 static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *host_col, int64_t first,
@@ -513,28 +499,21 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     }
     const int64_t shift = first - ((int64_t)m->h_rowstr_local[0] - 1);
     spmv_striped_host th;
+    spmv_striped_opts so;
+    spmv_striped_default_opts(&so);
+    so.target_wgs = g_stripe_wgs;
+    so.groups = g_stripe_groups;
+    so.wave_rows = g_stripe_wave_rows;
     int rc = m->cols < 16 ? -2
                           : spmv_striped_build((const char *)host_a + shift * m->elem, m->h_rowstr_local,
-                                               host_col + shift, 0, m->rows, m->cols, m->elem, g_stripe_xbytes,
-                                               g_stripe_wpb, g_stripe_wgs, g_stripe_epl, &th);
+                                               host_col + shift, 0, m->rows, m->cols, m->elem, &so, &th);
     free(tmp_a), free(tmp_c);
     /* many (row, stripe) pairs are empty: the columns are local to the rows, x gathers already
      * hit in cache and the STREAM kernel is the better plan (measured: 73 us vs 133 us; with only two
      * stripes a banded matrix leaves just under half of the pairs empty, hence 40 %, while scattered
-     * columns at the 1.6-per-segment limit of spmv_plan_choose leave 20 %) */
-    m->striped_mostly_filler = rc == 0 && th.n_dummies * 5 >= 2 * (int64_t)th.S * m->rows; /* 40 % of the pairs */
-    if (rc == 0 && th.n_waves > 0) {
-        /* a (row, stripe) segment is never split between waves: one dense row makes one wave per stripe
-         * run many times longer than the rest, and the kernel as long as that wave.  STREAM cuts long
-         * rows into segments; leave such matrices to it. */
-        int64_t longest = 0;
-        for (int i = 0; i < th.n_waves; ++i) {
-            const int64_t len = (int64_t)th.wptr[i + 1] - th.wptr[i];
-            longest = len > longest ? len : longest;
-        }
-        if (longest * th.n_waves > 2 * th.n_packed + 256 * (int64_t)th.n_waves * th.EPL)
-            m->striped_mostly_filler = true; /* same consequence: AUTO declines */
-    }
+     * columns at the 1.6-per-segment limit of spmv_plan_choose leave 20 %); or one dense row makes a tile
+     * many times longer than the rest (STREAM cuts long rows into segments) */
+    m->striped_mostly_filler = rc == 0 && (th.n_dummies * 5 >= 2 * (int64_t)th.S * m->rows || th.skewed);
     if (auto_choice && m->striped_mostly_filler) {
         spmv_striped_free(&th);
         rc = -2;
@@ -548,35 +527,35 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         spmv_set_error("matrix not representable in the STRIPED layout or not suited to it");
         return -2;
     }
-    const size_t nw = (size_t)th.n_waves;
+    const size_t ntp = (size_t)th.NG * (size_t)th.n_ranges * ((size_t)th.GM + 1);
     const size_t n_alloc = (size_t)th.n_packed + SPMV_TILE_PAD;
-    const size_t pbytes = (size_t)th.S * (size_t)m->rows * (size_t)m->elem;
-    void *d_w = nullptr, *d_r = nullptr, *d_c = nullptr, *d_v = nullptr, *d_p = nullptr;
-    hipError_t e = hipMalloc(&d_w, (nw + 1) * sizeof(int32_t));
+    const size_t pbytes = th.NG > 1 ? (size_t)th.NG * (size_t)m->rows * (size_t)m->elem + 64 : 0;
+    void *d_t = nullptr, *d_r = nullptr, *d_c = nullptr, *d_v = nullptr, *d_p = nullptr;
+    hipError_t e = hipMalloc(&d_t, ntp * sizeof(int32_t));
     if (e == hipSuccess)
-        e = hipMalloc(&d_r, (nw + 1) * sizeof(int32_t));
+        e = hipMalloc(&d_r, ((size_t)th.n_ranges + 1) * sizeof(int32_t));
     if (e == hipSuccess)
         e = hipMalloc(&d_c, n_alloc * sizeof(uint16_t));
     if (e == hipSuccess)
         e = hipMalloc(&d_v, n_alloc * (size_t)m->elem);
+    if (e == hipSuccess && pbytes)
+        e = hipMalloc(&d_p, pbytes);
     if (e == hipSuccess)
-        e = hipMalloc(&d_p, pbytes + 64);
+        e = hipMemcpy(d_t, th.tptr, ntp * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
-        e = hipMemcpy(d_w, th.wptr, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_r, th.wrow, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+        e = hipMemcpy(d_r, th.rrow, ((size_t)th.n_ranges + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         spmv_set_error("STRIPED upload failed: %s", hipGetErrorString(e));
-        (void)hipFree(d_w), (void)hipFree(d_r), (void)hipFree(d_c), (void)hipFree(d_v), (void)hipFree(d_p);
+        (void)hipFree(d_t), (void)hipFree(d_r), (void)hipFree(d_c), (void)hipFree(d_v), (void)hipFree(d_p);
         spmv_striped_free(&th);
         return -1;
     }
-    m->ds.wptr = (const int32_t *)d_w;
-    m->ds.wrow = (const int32_t *)d_r;
+    m->ds.tptr = (const int32_t *)d_t;
+    m->ds.rrow = (const int32_t *)d_r;
     m->ds.col = (const uint16_t *)d_c;
     m->ds.val = d_v;
     m->ds.partial = d_p;
@@ -584,125 +563,18 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     m->ds.W = th.W;
     m->ds.S = th.S;
     m->ds.WPB = th.WPB;
-    m->ds.B = th.B;
+    m->ds.NB = th.NB;
+    m->ds.NG = th.NG;
+    m->ds.GM = th.GM;
     m->ds.EPL = th.EPL;
-    m->ds.xbytes = g_stripe_xbytes;
+    m->ds.n_ranges = th.n_ranges;
+    m->ds.wave_rows = so.wave_rows;
+    m->ds.xbytes = so.xbytes;
     m->ds.rows = m->rows;
     m->ds.cols = m->cols;
-    m->device_bytes += (nw + 1) * 8 + n_alloc * (2 + (size_t)m->elem) + pbytes;
+    m->device_bytes += ntp * 4 + ((size_t)th.n_ranges + 1) * 4 + n_alloc * (2 + (size_t)m->elem) + pbytes;
     m->have_striped = true;
     spmv_striped_free(&th);
-    return 0;
-}
-
-/* LANES: same flow as ensure_striped (host_a == nullptr: fetch the CSR arrays back from the device) */
-static int ensure_lanes(spmv_hip_matrix *m, const void *host_a, const int *host_col, int64_t first, bool auto_choice)
-{
-    if (m->have_lanes) {
-        if (auto_choice && m->lanes_mostly_pad) {
-            m->lanes_rc = -2;
-            return -2;
-        }
-        return 0;
-    }
-    void *tmp_a = nullptr;
-    int *tmp_c = nullptr;
-    if (!host_a) {
-        tmp_a = malloc((size_t)(m->nnz ? m->nnz : 1) * m->elem);
-        tmp_c = (int *)malloc((size_t)(m->nnz ? m->nnz : 1) * sizeof(int));
-        if (!tmp_a || !tmp_c) {
-            free(tmp_a), free(tmp_c);
-            spmv_set_error("out of host memory for the LANES conversion");
-            return -1;
-        }
-        hipStream_t st = g_dev[m->device].stream;
-        if (m->nnz > 0) {
-            HIPCHK(hipMemcpyAsync(tmp_a, m->d_val, (size_t)m->nnz * m->elem, hipMemcpyDeviceToHost, st),
-                   { free(tmp_a); free(tmp_c); return -1; });
-            HIPCHK(hipMemcpyAsync(tmp_c, m->d_col, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost, st),
-                   { free(tmp_a); free(tmp_c); return -1; });
-        }
-        HIPCHK(hipStreamSynchronize(st), { free(tmp_a); free(tmp_c); return -1; });
-        host_a = tmp_a;
-        host_col = tmp_c;
-        first = 0;
-    }
-    const int64_t shift = first - ((int64_t)m->h_rowstr_local[0] - 1);
-    spmv_lanes_host th;
-    const int wpb = g_stripe_wpb == 8 && g_stripe_xbytes == 65536 ? 8 : 16; /* the instantiated shapes */
-    int rc = m->cols < 16 ? -2
-                          : spmv_lanes_build((const char *)host_a + shift * m->elem, m->h_rowstr_local,
-                                             host_col + shift, 0, m->rows, m->cols, m->elem, g_stripe_xbytes, wpb,
-                                             g_stripe_wgs, &th);
-    free(tmp_a), free(tmp_c);
-    /* padding beyond 1/8 of the nonzeros: the lanes of a wave are too uneven (few rows per wave, or
-     * a handful of rows far longer than the rest) */
-    m->lanes_mostly_pad = rc == 0 && th.n_pad * 8 > m->nnz;
-    if (auto_choice && m->lanes_mostly_pad) {
-        spmv_lanes_free(&th);
-        rc = -2;
-    }
-    m->lanes_rc = rc;
-    if (rc == -1) {
-        spmv_set_error("out of host memory for the LANES conversion");
-        return -1;
-    }
-    if (rc == -2) {
-        spmv_set_error("matrix not representable in the LANES layout or not suited to it");
-        return -2;
-    }
-    const size_t nw = (size_t)th.n_waves;
-    const size_t n_alloc = (size_t)th.n_packed + SPMV_TILE_PAD;
-    const size_t sr = (size_t)th.S * (size_t)m->rows;
-    const size_t pbytes = ((size_t)th.n_slots + 64) * (size_t)m->elem;
-    void *d_w = nullptr, *d_s = nullptr, *d_i = nullptr, *d_c = nullptr, *d_v = nullptr, *d_p = nullptr;
-    hipError_t e = hipMalloc(&d_w, (nw + 1) * sizeof(int32_t));
-    if (e == hipSuccess)
-        e = hipMalloc(&d_s, (nw + 1) * sizeof(int32_t));
-    if (e == hipSuccess)
-        e = hipMalloc(&d_i, (sr + 1) * sizeof(int32_t));
-    if (e == hipSuccess)
-        e = hipMalloc(&d_c, n_alloc * sizeof(uint16_t));
-    if (e == hipSuccess)
-        e = hipMalloc(&d_v, n_alloc * (size_t)m->elem);
-    if (e == hipSuccess)
-        e = hipMalloc(&d_p, pbytes);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_w, th.wptr, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_s, th.wslot, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_i, th.islot, sr * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemset(d_p, 0, pbytes);
-    if (e != hipSuccess) {
-        spmv_set_error("LANES upload failed: %s", hipGetErrorString(e));
-        (void)hipFree(d_w), (void)hipFree(d_s), (void)hipFree(d_i), (void)hipFree(d_c), (void)hipFree(d_v);
-        (void)hipFree(d_p);
-        spmv_lanes_free(&th);
-        return -1;
-    }
-    m->dl.wptr = (const int32_t *)d_w;
-    m->dl.wslot = (const int32_t *)d_s;
-    m->dl.islot = (const int32_t *)d_i;
-    m->dl.col = (const uint16_t *)d_c;
-    m->dl.val = d_v;
-    m->dl.partial = d_p;
-    m->dl.elem = m->elem;
-    m->dl.W = th.W;
-    m->dl.S = th.S;
-    m->dl.WPB = th.WPB;
-    m->dl.B = th.B;
-    m->dl.xbytes = g_stripe_xbytes;
-    m->dl.rows = m->rows;
-    m->dl.cols = m->cols;
-    m->device_bytes += (nw + 1) * 8 + sr * 4 + n_alloc * (2 + (size_t)m->elem) + pbytes;
-    m->have_lanes = true;
-    spmv_lanes_free(&th);
     return 0;
 }
 
@@ -900,12 +772,6 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
         m->plan = plan;
         m->param = m->ds.W;
         break;
-    case SPMV_HIP_PLAN_LANES:
-        if (ensure_lanes(m, nullptr, nullptr, 0, false))
-            return -1;
-        m->plan = plan;
-        m->param = m->dl.W;
-        break;
     case SPMV_HIP_PLAN_ORDERED:
         m->plan = plan;
         m->param = 1;
@@ -939,8 +805,7 @@ static int n_launches(const spmv_hip_matrix *m)
 {
     int longk = m->sp.nseg > 0 ? 1 + (m->sp.nlrow > 0) : 0;
     switch (m->plan) {
-    case SPMV_HIP_PLAN_STRIPED: return 2;
-    case SPMV_HIP_PLAN_LANES: return 2;
+    case SPMV_HIP_PLAN_STRIPED: return m->ds.NG > 1 ? 2 : 1;
     case SPMV_HIP_PLAN_STREAM: return 1 + longk;
     case SPMV_HIP_PLAN_BINNED: {
         int n = longk;
@@ -968,8 +833,7 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     out->max_row_len = m->st.max_len;
     out->mean_row_len = m->st.mean_len;
     out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED     ? m->dt.B
-                    : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.S * m->ds.B
-                    : m->plan == SPMV_HIP_PLAN_LANES   ? m->dl.S * m->dl.B
+                    : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.NG * m->ds.NB
                                                        : m->sp.nblk;
     out->n_long_rows = m->sp.n_long_rows;
     out->n_launches = n_launches(m);
@@ -988,18 +852,16 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
 int spmvd_spmv_dot(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream, const void *v_dev,
                    void *dot_part)
 {
-    if (!m || m->rows == 0 || (m->plan != SPMV_HIP_PLAN_STRIPED && m->plan != SPMV_HIP_PLAN_LANES) ||
-        (reinterpret_cast<uintptr_t>(x_dev) & 15u) != 0)
+    if (!m || m->rows == 0 || m->plan != SPMV_HIP_PLAN_STRIPED || (reinterpret_cast<uintptr_t>(x_dev) & 15u) != 0)
         return 0;
     HIPCHK(hipSetDevice(m->device), return -1);
     hipStream_t st = stream_of(m->device, stream);
-    int rc = m->plan == SPMV_HIP_PLAN_LANES ? spmvk_lanes(&m->dl, x_dev, y_dev, st, v_dev, dot_part)
-                                            : spmvk_striped(&m->ds, x_dev, y_dev, st, v_dev, dot_part);
+    int rc = spmvk_striped(&m->ds, x_dev, y_dev, st, v_dev, dot_part);
     if (rc) {
         spmv_set_error("kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return -1;
     }
-    return (m->rows + SPMV_WG - 1) / SPMV_WG;
+    return m->ds.NG > 1 ? (m->rows + SPMV_WG - 1) / SPMV_WG : m->ds.n_ranges;
 }
 
 int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream)
@@ -1021,12 +883,10 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
     switch (m->plan) {
     case SPMV_HIP_PLAN_ORDERED: rc = spmvk_ordered(&d, x_dev, y_dev, st); break;
     case SPMV_HIP_PLAN_STRIPED:
-    case SPMV_HIP_PLAN_LANES:
     case SPMV_HIP_PLAN_TILED:
         if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0) {
-            rc = m->plan == SPMV_HIP_PLAN_TILED     ? spmvk_tiled(&m->dt, x_dev, y_dev, st)
-                 : m->plan == SPMV_HIP_PLAN_LANES   ? spmvk_lanes(&m->dl, x_dev, y_dev, st, nullptr, nullptr)
-                                                    : spmvk_striped(&m->ds, x_dev, y_dev, st, nullptr, nullptr);
+            rc = m->plan == SPMV_HIP_PLAN_TILED ? spmvk_tiled(&m->dt, x_dev, y_dev, st)
+                                                : spmvk_striped(&m->ds, x_dev, y_dev, st, nullptr, nullptr);
             break;
         }
         /* k_tiled stages x with 16-byte loads; a misaligned x goes to the row-segment kernel */
@@ -1099,14 +959,12 @@ void spmv_hip_set_tuning(int key, int value)
         spmv_tiled_set_xbytes(value);
     else if (key == 4)
         spmv_tiled_set_blocks(value);
-    else if (key == 7 && (value == 65536 || value == 131072))
-        g_stripe_xbytes = value;
-    else if (key == 8 && (value == 8 || value == 16))
-        g_stripe_wpb = value;
     else if (key == 9 && value > 0)
         g_stripe_wgs = value;
-    else if (key == 10 && (value == 4 || value == 8))
-        g_stripe_epl = value;
+    else if (key == 11 && value >= 0)
+        g_stripe_groups = value;
+    else if (key == 12 && value >= 64 && value <= SPMV_STRIPE_WAVE_ROWS && value % 64 == 0)
+        g_stripe_wave_rows = value;
     else
         spmvk_set_tuning(key, value);
 }

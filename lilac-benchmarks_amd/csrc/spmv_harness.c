@@ -44,7 +44,7 @@
  *                      compare: no page protection, every call compares the arrays byte for byte.
  *   SPMV_HIP_ZEROCOPY = 1 (default) | 0     vectors up to 1 MB cross PCIe through kernels
  *                                           reading / writing pinned host memory instead of DMA
- *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped | lanes
+ *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped
  *   SPMV_HIP_DEVICES = number of GPUs to row-partition over (default 1; "all")
  *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
  *                      than devices wraps around -- lets the multi-GPU code path
@@ -482,10 +482,8 @@ static void lazy_init(void)
             G.plan = SPMV_HIP_PLAN_TILED;
         else if (!strcmp(v, "striped"))
             G.plan = SPMV_HIP_PLAN_STRIPED;
-        else if (!strcmp(v, "lanes"))
-            G.plan = SPMV_HIP_PLAN_LANES;
         else if (strcmp(v, "auto"))
-            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped|lanes", v);
+            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped", v);
     }
     G.zero_copy = env_int("SPMV_HIP_ZEROCOPY", 1);
     G.stats = env_int("SPMV_HIP_STATS", 0);

@@ -120,44 +120,42 @@ void spmv_tiled_set_xbytes(int bytes);  /* experiments: 32768 (default) or 65536
 void spmv_tiled_set_blocks(int blocks); /* experiments: workgroups aimed for (0 = default) */
 
 /*
- * STRIPED plan (spmv_striped.c): 2-D decomposition, one column stripe of x per workgroup for its
- * whole life, row ends flagged in bit 15 of the 16-bit column, partial sums per (stripe, row).
+ * STRIPED plan (spmv_striped.c): 2-D decomposition, (stripe group, row block) per workgroup, a stripe of x in
+ * LDS at a time, row ends flagged in bit 15 of the 16-bit column, row sums carried in registers across the
+ * stripes of a group, one partial sum per (stripe group, row).
  */
 #define SPMV_STRIPE_XBYTES 131072  /* bytes of x per stripe (single LDS buffer, one workgroup/CU) */
 #define SPMV_STRIPE_WPB 16         /* waves per workgroup                                        */
 #define SPMV_STRIPE_TARGET_WGS 256 /* workgroups aimed for: one 160-KiB workgroup per CU          */
 #define SPMV_STRIPE_EPL 4          /* entries per lane per sub-window                            */
+#define SPMV_STRIPE_NACC 16        /* row accumulators per lane                                   */
+#define SPMV_STRIPE_WAVE_ROWS (64 * SPMV_STRIPE_NACC) /* rows a wave can carry across a stripe group */
+typedef struct spmv_striped_opts {
+    int xbytes;     /* LDS bytes of x per stripe                                     */
+    int wpb;        /* waves per workgroup                                           */
+    int target_wgs; /* workgroups aimed for (NB * NG)                                */
+    int wave_rows;  /* most rows per wave range (a multiple of 64)                   */
+    int groups;     /* stripe groups, 0 = choose                                     */
+} spmv_striped_opts;
 typedef struct spmv_striped_host {
-    int elem, W, S, WPB, B, n_waves;
-    int EPL;       /* entries per lane per sub-window (4 or 8); a sub-window = 64*EPL entries */
-    int64_t n_packed, n_dummies;
+    int elem, W, S, WPB, EPL;
+    int NB, NG, GM;  /* row blocks, stripe groups, most stripes per group                          */
+    int n_ranges;    /* NB * WPB wave ranges                                                         */
+    int cap;         /* elements of the kernel's LDS buffer; cap - 1 = the zero column               */
+    int skewed;      /* one tile dwarfs the others (a dense row): the automatic choice declines      */
+    int64_t n_packed, n_dummies, max_tile;
     void *val;
     uint16_t *col;
-    int32_t *wptr; /* [n_waves + 1] */
-    int32_t *wrow; /* [n_waves + 1] first row of each wave's range */
+    int32_t *tptr; /* [NG * n_ranges * (GM + 1)] tile starts, see spmv_striped.c */
+    int32_t *rrow; /* [n_ranges + 1] first row of each wave range               */
 } spmv_striped_host;
 
-void spmv_striped_geometry(int rows, int cols, int elem_size, int xbytes, int wpb, int target_wgs, int epl,
-                           spmv_striped_host *t);
+void spmv_striped_default_opts(spmv_striped_opts *o);
+void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped_opts *o, spmv_striped_host *t);
+/* opts == NULL: the defaults */
 int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,
-                       int elem_size, int xbytes, int wpb, int target_wgs, int epl, spmv_striped_host *t);
+                       int elem_size, const spmv_striped_opts *opts, spmv_striped_host *t);
 void spmv_striped_free(spmv_striped_host *t);
-
-/* LANES plan (spmv_lanes.c): the STRIPED decomposition with whole (row, stripe) segments dealt to
- * lanes; geometry (W, S, B, WPB) as spmv_striped_geometry with 4 entries per lane per sub-window. */
-#define SPMV_LANES_QUEUE 4 /* finished sums a lane can hold before its wave writes them out */
-typedef struct spmv_lanes_host {
-    int elem, W, S, WPB, B, n_waves;
-    int64_t n_packed, n_pad, n_slots;
-    void *val;
-    uint16_t *col;
-    int32_t *wptr;  /* [n_waves + 1] first entry of each wave's run (multiples of 256)     */
-    int32_t *wslot; /* [n_waves + 1] first partial-sum slot of each wave                    */
-    int32_t *islot; /* [S * rows]    slot of (stripe, row), -1 = no entry in that stripe    */
-} spmv_lanes_host;
-int spmv_lanes_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,
-                     int elem_size, int xbytes, int wpb, int target_wgs, spmv_lanes_host *t);
-void spmv_lanes_free(spmv_lanes_host *t);
 
 /* Adaptive choice (SPMV_HIP_PLAN_AUTO): fills *plan / *param from the row statistics. */
 void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *plan, int *param);
@@ -188,31 +186,21 @@ typedef struct spmv_dev_tiled {
 } spmv_dev_tiled;
 int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream);
 typedef struct spmv_dev_striped {
-    const int32_t *wptr;
-    const int32_t *wrow;
+    const int32_t *tptr;
+    const int32_t *rrow;
     const uint16_t *col;
     const void *val;
-    void *partial; /* T[S * rows] */
-    int elem, W, S, WPB, B, EPL, rows, cols;
-    int xbytes; /* LDS stripe capacity (65536 / 131072) the layout was built for */
+    void *partial;          /* T[NG * rows], NULL when NG == 1 */
+    int elem, W, S, WPB, NB, NG, GM, EPL, n_ranges, wave_rows, rows, cols;
+    int xbytes; /* LDS stripe capacity the layout was built for */
 } spmv_dev_striped;
-typedef struct spmv_dev_lanes {
-    const int32_t *wptr, *wslot, *islot;
-    const uint16_t *col;
-    const void *val;
-    void *partial; /* T[n_slots] */
-    int elem, W, S, WPB, B, rows, cols;
-    int xbytes;
-} spmv_dev_lanes;
-/* dotv as in spmvk_striped */
-int spmvk_lanes(const spmv_dev_lanes *t, const void *x, void *y, void *stream, const void *dotv, void *dot_part);
 struct spmv_hip_matrix;
 /* y = A x plus block partials of y . v when the plan can fold them in (STRIPED): returns the number
- * of partials (one per 256 rows), 0 = not folded (run a separate dot), -1 = error */
+ * of partials (one per wave range when a workgroup walks every stripe, else one per 256 rows; <= rows + 16), 0 = not folded (run a separate dot), -1 = error */
 int spmvd_spmv_dot(struct spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream, const void *v_dev,
                    void *dot_part);
 
-/* dotv != NULL: also dot_part[b] = sum over rows [256 b, 256 b + 256) of y[r] * dotv[r] */
+/* dotv != NULL: also dot_part[i] = sum of y[r] * dotv[r] over wave range i (NG == 1) or over rows [256 i, 256 i + 256) */
 int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *stream, const void *dotv,
                   void *dot_part);
 /* d_out[0] = max(colidx), d_out[1] = min(colidx); the caller presets {0, INT_MAX} */

@@ -29,10 +29,11 @@
  *   k_tiled     row blocks x column stripes with the stripe of x double-buffered in
  *               LDS; one lane per row adds in stored order (bit-exact on sorted
  *               columns).  Layout: spmv_tiled.c.
- *   k_striped   2-D decomposition, a workgroup keeps ONE stripe of x in LDS for its
- *               whole life and streams packed (value, 16-bit column) entries;
- *               k_stripe_sum adds the per-stripe partial sums.  Layout:
- *               spmv_striped.c.  The NPB class B/C/D kernel.
+ *   k_striped   2-D decomposition: a workgroup = (group of column stripes, row block) keeps a
+ *               stripe of x in LDS, streams packed (value, 16-bit column) entries and
+ *               carries row sums in registers across the stripes of its group; the last
+ *               wave to deliver a row range's partial sums adds them up (one launch).
+ *               Layout: spmv_striped.c.  The NPB class B/C/D kernel.
  *
  * Column ids stay 1-based as the ABI delivers them; kernels index x through
  * (x - 1).  a/colidx are over-allocated by SPMV_PAD_ELEMS entries (a = 0,
@@ -47,6 +48,7 @@ namespace {
 /* ---- tuning switches (set through spmvk_set_tuning; experiments only) ------- */
 int g_tune_xcd = 1;     /* give each XCD a contiguous range of row blocks        */
 int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx        */
+int g_tune_abl = 0;     /* k_striped ablation bits (timing experiments only; results are wrong when set) */
 int g_tune_tile_k = 0;  /* register sets of k_tiled (2,4,6,8; default 4) / k_striped (2,3,4; default 2) */
 
 /* ---- 16-byte vector types --------------------------------------------------- */
@@ -563,14 +565,18 @@ done:
 
 /* ================================ k_striped ===================================== */
 /*
- * STRIPED plan (layout: spmv_striped.c).  Workgroup = (stripe s, row range b): it copies its
- * stripe of x into LDS once, one barrier, and from then on every wave is on its own, streaming
- * its linear run of packed (value, flagged 16-bit column) entries through a ring of register sets
- * reloaded in place.  Per 256-entry sub-window: multiply by x from LDS, add each lane's four
- * entries up to the row-end flags, segmented scan over the wave (DPP) for the rows that span
- * lanes, and every row-end entry stores its row's partial sum for this stripe.  Rows are numbered
- * by counting flags (ballot + mbcnt): no row pointers are read.  Nothing is atomic; the order of
- * the additions is fixed by the layout.
+ * STRIPED plan (layout: spmv_striped.c).  Workgroup = (stripe group g, row block rb).  It walks the
+ * stripes of its group: copy the stripe of x into LDS (one staging, two LDS-only barriers), then
+ * every wave is on its own until the stripe ends, streaming the tile of ITS rows -- packed (value,
+ * flagged 16-bit column) entries -- through a ring of register sets reloaded in place; the wave's
+ * tiles follow each other in memory, so the ring simply runs on across stripe changes.  Per
+ * 256-entry sub-window: multiply by x from LDS, add each lane's four entries up to the row-end
+ * flags, segmented scan over the wave (DPP) for the rows that span lanes; rows are numbered by
+ * counting flags (ballot + mbcnt): no row pointers are read.  A finished (row, stripe) sum is parked
+ * in the wave's LDS ring and leaves it 64 rows at a time INTO REGISTERS: accumulator k of lane l
+ * belongs to row 64 k + l of the wave's range and lives across all stripes of the group.  After the
+ * group the accumulators are y (NG = 1) or the group's partial sums, which k_group_sum adds in group
+ * order.  Nothing is atomic; the order of every addition is fixed by the layout.
  */
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_mov(int v)
 {
@@ -608,115 +614,88 @@ __device__ __forceinline__ void stripe_load(StripeRegs<T, EPL> &r, const T *__re
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E;
     const unsigned int base = (unsigned int)sb;
-    if constexpr (EPL == 4) {
-        const u32x2 cc = *reinterpret_cast<const u32x2 *>(pcol + base + (unsigned int)lane * 4u);
-        r.c[0] = cc[0], r.c[1] = cc[1];
-    } else {
-        const i32x4 cc = *reinterpret_cast<const i32x4 *>(pcol + base + (unsigned int)lane * 8u);
-        r.c[0] = (unsigned int)cc[0], r.c[1] = (unsigned int)cc[1];
-        r.c[2] = (unsigned int)cc[2], r.c[3] = (unsigned int)cc[3];
-    }
+    static_assert(EPL == 4, "one 8-byte column load per lane");
+    const u32x2 cc = *reinterpret_cast<const u32x2 *>(pcol + base + (unsigned int)lane * 4u);
+    r.c[0] = cc[0], r.c[1] = cc[1];
 #pragma unroll
     for (int j = 0; j < StripeRegs<T, EPL>::NV; ++j)
         r.v[j] = *reinterpret_cast<const VT *>(pval + base + (unsigned int)(j * 64 * E) + (unsigned int)lane * E);
 }
 
-/*
- * A global store the compiler's wait-count bookkeeping does not see.  gfx950 has one counter
- * (vmcnt) for vector loads AND stores; with a data-dependent number of stores in the loop the
- * compiler can no longer tell how many operations are younger than a load, and waits vmcnt(0)
- * before every use -- which also drains the loads of the NEXT register set and collapses the
- * ring to depth one.  The partial sums written here are never read back by this kernel, so the
- * store needs no wait at all; counting only the loads, the compiler's vmcnt(N) stays correct
- * (loads return in order among themselves: once N + #stores operations remain outstanding at
- * most, with at most #stores of them stores, the load being waited for is back).
- */
-__device__ __forceinline__ void store_untracked(double *p, double v)
+/* acc[k] += v in the lanes where pred holds.  k is wave-uniform (made so with readfirstlane), which lets the
+ * compiler address the register array through s_set_gpr_idx_on: two indexed moves out, one add, two moves back,
+ * instead of sixteen copies of the add behind a branch tree (9000 lines of ISA: more than the instruction
+ * cache) or an array in scratch memory. */
+template <typename T, int NACC> __device__ __forceinline__ void acc_add(T (&acc)[NACC], unsigned int k, T v, bool pred)
 {
-    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void store_untracked(float *p, float v)
-{
-    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+    const int ki = __builtin_amdgcn_readfirstlane((int)k) & (NACC - 1);
+    const T cur = acc[ki];
+    acc[ki] = pred ? cur + v : cur;
 }
 
-template <typename T, int WPB, int R, int XT_BYTES, int EPL>
-__global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__ wptr,
-                                                         const int *__restrict__ wrow,
-                                                         const unsigned short *__restrict__ pcol,
-                                                         const T *__restrict__ pval,
-                                                         const T *__restrict__ x, T *__restrict__ partial,
-                                                         int rows, int cols, int B, int wcols)
+template <typename T, int WPB, int R, int XT_BYTES, int EPL, int NACC>
+__global__ void __launch_bounds__(WPB * 64, 4)
+k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const unsigned short *__restrict__ pcol,
+          const T *__restrict__ pval, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ partial,
+          const T *__restrict__ dotv, T *__restrict__ dot_part, int rows,
+          int cols, int S, int NB, int NG, int GM, int wcols, int nwg, int per_xcd, int abl)
 {
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E;
-    constexpr int W = XT_BYTES / (int)sizeof(T);
+    constexpr int W = XT_BYTES / (int)sizeof(T); /* elements of the LDS buffer; W - 1 is the zero column */
     constexpr int SUB = 64 * EPL;
     constexpr int NT = WPB * 64;
     constexpr int XV = W / (NT * E);
     static_assert(XV * NT * E == W, "stripe must be a whole number of 16-byte loads per thread");
     static_assert((R + 1) * SUB <= SPMV_TILE_PAD, "look-ahead must stay inside the padding");
-    constexpr int RING = 256; /* row sums staged per wave before they leave as full 64-lane stores */
+    static_assert(R >= 2 && R <= 4, "ring depth");
+    constexpr int RING = 256; /* row sums staged per wave before they are taken into the accumulators */
     __shared__ __attribute__((aligned(16))) T s_x[W];
     __shared__ __attribute__((aligned(16))) T s_out[WPB][RING];
 
+    const int q = per_xcd ? xcd_contiguous((int)blockIdx.x, per_xcd) : (int)blockIdx.x;
+    if (q >= nwg)
+        return; /* the whole workgroup */
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int s = blockIdx.x / B; /* stripe */
-    const int wi = blockIdx.x * WPB + w;
-    const int P0 = __builtin_amdgcn_readfirstlane(wptr[wi]);
-    const int P1 = __builtin_amdgcn_readfirstlane(wptr[wi + 1]); /* P1 - P0 is a multiple of SUB */
-    unsigned int row = (unsigned int)__builtin_amdgcn_readfirstlane(wrow[wi]);
+    const int g = q / NB, rb = q - g * NB;
+    const int u = rb * WPB + w; /* wave range */
+    const int row0 = __builtin_amdgcn_readfirstlane(rrow[u]);
+    const unsigned int nr = (unsigned int)(__builtin_amdgcn_readfirstlane(rrow[u + 1]) - row0);
+    const int s0 = (int)((long long)g * S / NG), s1 = (int)((long long)(g + 1) * S / NG);
+    const int *__restrict__ tp = tptr + ((size_t)g * (size_t)(NB * WPB) + (size_t)u) * (size_t)(GM + 1);
+
+    T acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+        acc[k] = (T)0;
 
     /* the first R sub-windows are on their way while x is staged */
+    int P = __builtin_amdgcn_readfirstlane(tp[0]);
     StripeRegs<T, EPL> set[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        stripe_load<T, EPL>(set[r], pval, pcol, P0 + r * SUB, lane);
+        stripe_load<T, EPL>(set[r], pval, pcol, P + r * SUB, lane);
 
-    {
-        const int c0 = s * wcols; /* wcols <= W columns per stripe (spmv_striped_geometry) */
-        const int nx = (cols - c0) < wcols ? (cols - c0) : wcols;
-        const T *xs = x + c0;
-        VT xr[XV];
-#pragma unroll
-        for (int k = 0; k < XV; ++k) {
-            const int i = (k * NT + tid) * E;
-            const T *src = (i + E <= nx) ? xs + i : x; /* no branch around a load; see k_tiled */
-            xr[k] = *reinterpret_cast<const VT *>(src);
-        }
-#pragma unroll
-        for (int k = 0; k < XV; ++k)
-            *reinterpret_cast<VT *>(&s_x[(k * NT + tid) * E]) = xr[k];
-        const int tail = nx % E; /* <16-byte tail of the last stripe: patched by the slot's owner */
-        if (tail != 0 && (((nx - tail) / E) % NT) == tid)
-            for (int j = 0; j < tail; ++j)
-                s_x[nx - tail + j] = xs[nx - tail + j];
-        if (tid == NT - 1) /* the thread that wrote the buffer's last 16 bytes: fillers multiply with 0 */
-            s_x[W - 1] = (T)0;
-    }
-    wg_barrier_lds();
+    /* per-stripe state of the wave */
+    unsigned int row = 0, flushed = 0; /* local row numbers: next row to end, first row still in the ring */
+    T carry = (T)0;                    /* open sum of the row that spans the sub-window boundary */
 
-    T *__restrict__ out = partial + (size_t)s * (size_t)rows;
-    T carry = (T)0; /* open sum of the row that spans the sub-window boundary */
-    /*
-     * Row sums do not go to memory one by one (a store per row end costs more than the loads):
-     * rows are consecutive, so they are parked in the wave's LDS ring at (row & 255) and leave 64
-     * at a time as one coalesced store.  `flushed` = first row not yet written.
-     */
-    unsigned int flushed = row;
-    auto flush64 = [&]() {
-        const T v = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
-        store_untracked(out + (flushed + (unsigned int)lane), v);
-        flushed += 64;
+    /* rows [a, b) leave the ring for the accumulators; a is a multiple of 64 (it always is: see below), b - a <= 64:
+     * lane l takes row a + l into accumulator a / 64 */
+    auto take = [&](const unsigned int a, const unsigned int b) __attribute__((always_inline)) {
+        const unsigned int r = a + (unsigned int)lane;
+        if (abl & 4)
+            return;
+        const T v = s_out[w][r & (RING - 1)];
+        acc_add<T, NACC>(acc, a >> 6, v, r < b);
     };
+
     /*
      * One sub-window.  The main loop below calls this R times per trip with no exit in between, so
      * the R register sets stay a static ring (no copies, and the compiler can count the loads in
-     * flight: it waits for exactly the set it consumes); the last nsub % R sub-windows run after the
-     * loop, without reloading.
+     * flight: it waits for exactly the set it consumes).
      */
-    auto sub_window = [&](StripeRegs<T, EPL> &regs, const int sb, const bool reload)
-                          __attribute__((always_inline)) {
+    auto sub_window = [&](StripeRegs<T, EPL> &regs, const int sb) __attribute__((always_inline)) {
         T p[EPL];
         int f[EPL];
 #pragma unroll
@@ -725,8 +704,7 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__
             p[k] = regs.val(k) * s_x[c & (W - 1)];
             f[k] = (int)(c >> 15);
         }
-        if (reload) /* compile-time at every call site */
-            stripe_load<T, EPL>(regs, pval, pcol, sb + R * SUB, lane);
+        stripe_load<T, EPL>(regs, pval, pcol, sb + R * SUB, lane); /* may run into the wave's next tile: same stream */
         /* lane-local: the sum after the lane's last row end, and whether it has a row end */
         T tailv = (T)0;
         int has = 0;
@@ -762,257 +740,158 @@ __global__ void __launch_bounds__(WPB * 64, 4) k_striped(const int *__restrict__
                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0));
             nflags += (unsigned int)__builtin_popcountll(m);
         }
-        /* emit the rows that end in this lane */
-        T run = cin;
-        unsigned int idx = row + before;
-        if (nflags <= RING - 64) { /* wave-uniform; the ring holds < 64 pending rows here */
+        /*
+         * Park the sums of the rows that end in this lane in the wave's ring (slot = row number mod 256), then
+         * take whole groups of 64 rows out of it.  The ring holds < 64 rows from earlier sub-windows and this
+         * one adds up to 256: rows beyond the ring's reach (a sub-window crowded with one-entry rows) wait for
+         * a second pass, after the first has emptied the ring down to < 64 rows again -- `flushed` stays a
+         * multiple of 64, so every take() is one indexed accumulator.
+         */
+        const unsigned int flushed0 = flushed, row_new = row + nflags;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            T run = cin;
+            unsigned int idx = row + before;
 #pragma unroll
             for (int k = 0; k < EPL; ++k) {
                 run = run + p[k];
                 if (f[k]) {
-                    s_out[w][idx & (RING - 1)] = run;
+                    if ((idx - flushed0 >= (unsigned int)RING) == (pass == 1) && !(abl & 8))
+                        s_out[w][idx & (RING - 1)] = run;
                     ++idx;
                     run = (T)0;
                 }
             }
-            row += nflags;
+            const unsigned int present = pass == 0 && row_new - flushed0 > (unsigned int)RING ? flushed0 + RING : row_new;
             __builtin_amdgcn_wave_barrier();
-            while (row - flushed >= 64u)
-                flush64();
-            __builtin_amdgcn_wave_barrier();
-        } else { /* a sub-window crowded with tiny rows: drain the ring, then store directly */
-            if ((unsigned int)lane < row - flushed)
-                store_untracked(out + (flushed + (unsigned int)lane),
-                                s_out[w][(flushed + (unsigned int)lane) & (RING - 1)]);
-#pragma unroll
-            for (int k = 0; k < EPL; ++k) {
-                run = run + p[k];
-                if (f[k]) {
-                    store_untracked(out + idx, run);
-                    ++idx;
-                    run = (T)0;
-                }
+            while (present - flushed >= 64u) {
+                take(flushed, flushed + 64u);
+                flushed += 64u;
             }
-            row += nflags;
-            flushed = row;
+            __builtin_amdgcn_wave_barrier();
+            if (row_new - flushed0 <= (unsigned int)RING) /* wave-uniform: nearly always */
+                break;
         }
+        row = row_new;
     };
-    const int nsub = (P1 - P0) / SUB;
-    int j = 0;
-    for (; j + R <= nsub; j += R) {
+
+    for (int si = 0; s0 + si < s1; ++si) {
+        /* ---- the stripe of x into LDS ---- */
+        {
+            const int c0 = (s0 + si) * wcols; /* wcols <= W - 16/sizeof(T) columns per stripe (spmv_striped_geometry) */
+            const int nx = (cols - c0) < wcols ? (cols - c0) : wcols;
+            const T *xs = x + c0;
+            VT xr[XV];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            sub_window(set[r], P0 + (j + r) * SUB, true);
+            for (int k = 0; k < XV; ++k) {
+                const int i = (k * NT + tid) * E;
+                const T *src = (i + E <= nx) ? xs + i : x; /* no branch around a load; see k_tiled */
+                xr[k] = *reinterpret_cast<const VT *>(src);
+            }
+            if (si > 0)
+                wg_barrier_lds(); /* every wave is done with the previous stripe */
+#pragma unroll
+            for (int k = 0; k < XV; ++k)
+                *reinterpret_cast<VT *>(&s_x[(k * NT + tid) * E]) = xr[k];
+            const int tail = nx % E; /* <16-byte tail of the last stripe: patched by the slot's owner */
+            if (tail != 0 && (((nx - tail) / E) % NT) == tid)
+                for (int j = 0; j < tail; ++j)
+                    s_x[nx - tail + j] = xs[nx - tail + j];
+            if (tid == NT - 1) /* the thread that wrote the buffer's last 16 bytes: fillers and pads multiply with 0 */
+                s_x[W - 1] = (T)0;
+            wg_barrier_lds();
+        }
+        /* ---- the wave's tile ---- */
+        const int Pend = __builtin_amdgcn_readfirstlane(tp[si + 1]);
+        const int nsub = (Pend - P) / SUB;
+        row = 0, flushed = 0, carry = (T)0;
+        int j = 0;
+        for (; j + R <= nsub; j += R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                sub_window(set[r], P + (j + r) * SUB);
+        }
+        /* the last nsub % R sub-windows, then turn the ring so that set[0] is again the next sub-window */
+#pragma unroll
+        for (int k = 1; k < R; ++k)
+            if (nsub - j == k) { /* wave-uniform */
+#pragma unroll
+                for (int r = 0; r < k; ++r)
+                    sub_window(set[r], P + (j + r) * SUB);
+                StripeRegs<T, EPL> tmp[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+                    tmp[i] = set[(i + k) % R];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+                    set[i] = tmp[i];
+            }
+        P = Pend;
+        __builtin_amdgcn_wave_barrier();
+        take(flushed, row); /* the last < 64 rows of the tile */
+        __builtin_amdgcn_wave_barrier();
     }
+
+    /* ---- the group is done: acc[k] of lane l is the sum of local row 64 k + l over the group's stripes ---- */
+    const bool folded = dotv != nullptr; /* kernel-uniform */
+    T dot = (T)0;
+    if (NG == 1) {
 #pragma unroll
-    for (int r = 0; r < R - 1; ++r)
-        if (j + r < nsub) /* wave-uniform */
-            sub_window(set[r], P0 + (j + r) * SUB, false);
-    __builtin_amdgcn_wave_barrier();
-    if ((unsigned int)lane < row - flushed) /* the last < 64 rows of the wave's range */
-        out[flushed + (unsigned int)lane] = s_out[w][(flushed + (unsigned int)lane) & (RING - 1)];
+        for (int k = 0; k < NACC; ++k) {
+            const unsigned int r = 64u * k + (unsigned int)lane;
+            if (r < nr) {
+                y[row0 + r] = acc[k];
+                if (folded)
+                    dot = fmadd(acc[k], dotv[row0 + r], dot);
+            }
+        }
+    } else { /* the group's partial sums; k_group_sum adds the groups in order */
+        T *__restrict__ out = partial + (size_t)g * (size_t)rows + row0;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            const unsigned int r = 64u * k + (unsigned int)lane;
+            if (r < nr)
+                out[r] = acc[k];
+        }
+        return;
+    }
+    if (folded) { /* dot_part[u] = sum over the wave range of y[r] * dotv[r]: per lane in row order, then a butterfly */
+        for (int o = 32; o; o >>= 1)
+            dot += __shfl_xor(dot, o, 64);
+        if (lane == 0)
+            dot_part[u] = dot;
+    }
 }
 
-/* y[r] = sum of the S partial sums of row r, in stripe order.  With `dotv` the kernel also leaves
+/* y[r] = sum of the NG group partials of row r, in group order.  With `dotv` the kernel also leaves
  * dot_part[block] = sum over the block's rows of y[r] * dotv[r] (fixed order: wave butterfly, then the
- * four waves in order) -- the p.q of a CG step without another pass over y (spmv_cg.hip). */
+ * four waves in order) -- the p.q of a CG step without another pass over y (spmv_cg.hip).
+ *
+ * Why a second launch and not the last workgroup to arrive (tried in round 2, profiles/r02_kbench_fold_ablation.log):
+ * the waves of a launch finish together, so whoever adds up a row range does it on the critical path, after
+ * store -> drain -> arrival counter -> acquire -> loads; one wave per range pulling NG * rows-per-range values
+ * took 19 us on class C and 45 us on a class D row block, against 5-8 us for this kernel on the whole chip. */
 template <typename T>
-__global__ void __launch_bounds__(SPMV_WG) k_stripe_sum(const T *__restrict__ partial, T *__restrict__ y,
-                                                        int rows, int S, const T *__restrict__ dotv,
-                                                        T *__restrict__ dot_part)
+__global__ void __launch_bounds__(SPMV_WG) k_group_sum(const T *__restrict__ partial, T *__restrict__ y,
+                                                       int rows, int NG, const T *__restrict__ dotv,
+                                                       T *__restrict__ dot_part)
 {
     const int r = blockIdx.x * SPMV_WG + threadIdx.x;
     T acc = (T)0;
     if (r < rows) {
         const T *p = partial + r;
-        int s = 0;
-        for (; s + 8 <= S; s += 8) { /* eight loads in flight, added in stripe order */
+        int g = 0;
+        for (; g + 8 <= NG; g += 8) { /* eight loads in flight, added in group order */
             T v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                v[k] = p[(size_t)(s + k) * rows];
+                v[k] = p[(size_t)(g + k) * rows];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 acc = acc + v[k];
         }
-        for (; s < S; ++s)
-            acc = acc + p[(size_t)s * rows];
-        y[r] = acc;
-    }
-    if (dotv) { /* kernel-uniform */
-        __shared__ T s_w[SPMV_WG / 64];
-        T d = r < rows ? acc * dotv[r] : (T)0;
-        for (int o = 32; o; o >>= 1)
-            d += __shfl_xor(d, o, 64);
-        if ((threadIdx.x & 63) == 0)
-            s_w[threadIdx.x >> 6] = d;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            dot_part[blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
-    }
-}
-
-/* ================================ k_lanes ======================================= */
-/*
- * LANES plan (layout: spmv_lanes.c).  Workgroup = (stripe s, row range b) as in k_striped: stage
- * the stripe of x into LDS once, one barrier, then every wave streams its run of packed entries
- * through a static ring of register sets.  The difference is what a lane does with its four
- * entries of a sub-window: they are consecutive entries of the lane's OWN stream of whole
- * (row, stripe) segments, so it just multiplies and adds; at a flagged entry the sum of the lane's
- * k-th segment is finished and belongs into slot wslot + 64 k + lane.  It waits in the lane's own
- * 4-deep LDS queue until every lane of the wave is past its k-th segment, then the wave writes the 64
- * sums of group k with one coalesced store (scattered 8-byte stores, one per segment, cost 15 us on
- * class C).  A lane that is 4 or more groups ahead of the write-out stores directly and sets bit k
- * of a mask so that the group's write-out leaves its slot alone (the layout guarantees < 32 ahead).
- * About 50 vector instructions per 256 entries instead of 150, no cross-lane data traffic.
- */
-template <typename T, int WPB, int R, int XT_BYTES>
-__global__ void __launch_bounds__(WPB * 64, 4) k_lanes(const int *__restrict__ wptr, const int *__restrict__ wslot,
-                                                       const unsigned short *__restrict__ pcol,
-                                                       const T *__restrict__ pval, const T *__restrict__ x,
-                                                       T *__restrict__ partial, int cols, int B, int wcols)
-{
-    using VT = typename Vec16<T>::val_t;
-    constexpr int E = Vec16<T>::E;
-    constexpr int EPL = 4;
-    constexpr int W = XT_BYTES / (int)sizeof(T);
-    constexpr int SUB = 64 * EPL;
-    constexpr int NT = WPB * 64;
-    constexpr int XV = W / (NT * E);
-    constexpr int Q = SPMV_LANES_QUEUE;
-    static_assert(XV * NT * E == W, "stripe must be a whole number of 16-byte loads per thread");
-    static_assert((R + 1) * SUB <= SPMV_TILE_PAD, "look-ahead must stay inside the padding");
-    static_assert((Q & (Q - 1)) == 0, "queue depth must be a power of two");
-    __shared__ __attribute__((aligned(16))) T s_x[W];
-    __shared__ __attribute__((aligned(16))) T s_q[WPB][Q][64];
-
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int s = blockIdx.x / B; /* stripe */
-    const int wi = blockIdx.x * WPB + w;
-    const int P0 = __builtin_amdgcn_readfirstlane(wptr[wi]);
-    const int P1 = __builtin_amdgcn_readfirstlane(wptr[wi + 1]); /* P1 - P0 is a multiple of SUB */
-    const unsigned int slot0 = (unsigned int)__builtin_amdgcn_readfirstlane(wslot[wi]);
-    const unsigned int ngroups = ((unsigned int)__builtin_amdgcn_readfirstlane(wslot[wi + 1]) - slot0) >> 6;
-
-    StripeRegs<T, EPL> set[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        stripe_load<T, EPL>(set[r], pval, pcol, P0 + r * SUB, lane);
-
-    {
-        const int c0 = s * wcols;
-        const int nx = (cols - c0) < wcols ? (cols - c0) : wcols;
-        const T *xs = x + c0;
-        VT xr[XV];
-#pragma unroll
-        for (int k = 0; k < XV; ++k) {
-            const int i = (k * NT + tid) * E;
-            const T *src = (i + E <= nx) ? xs + i : x; /* no branch around a load; see k_tiled */
-            xr[k] = *reinterpret_cast<const VT *>(src);
-        }
-#pragma unroll
-        for (int k = 0; k < XV; ++k)
-            *reinterpret_cast<VT *>(&s_x[(k * NT + tid) * E]) = xr[k];
-        const int tail = nx % E;
-        if (tail != 0 && (((nx - tail) / E) % NT) == tid)
-            for (int j = 0; j < tail; ++j)
-                s_x[nx - tail + j] = xs[nx - tail + j];
-    }
-    wg_barrier_lds();
-
-    T *__restrict__ out = partial + slot0;
-    T acc = (T)0;
-    unsigned int kseg = 0;     /* segments this lane has finished                                  */
-    unsigned int direct = 0;   /* bit (k & 31): segment k went straight to memory                  */
-    unsigned int gflushed = 0; /* wave-uniform: groups already written out                         */
-    auto write_out = [&]() __attribute__((always_inline)) { /* group gflushed leaves the queues */
-        const T v = s_q[w][gflushed & (Q - 1)][lane];
-        if (!((direct >> (gflushed & 31u)) & 1u))
-            store_untracked(out + (gflushed * 64u + (unsigned int)lane), v);
-        direct &= ~(1u << (gflushed & 31u));
-        ++gflushed;
-    };
-    auto sub_window = [&](StripeRegs<T, EPL> &regs, const int sb, const bool reload)
-                          __attribute__((always_inline)) {
-        T v[EPL], xv[EPL];
-        unsigned int c[EPL];
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            c[k] = regs.col(k);
-            v[k] = regs.val(k);
-            xv[k] = s_x[c[k] & (W - 1)];
-        }
-        if (reload) /* compile-time at every call site */
-            stripe_load<T, EPL>(regs, pval, pcol, sb + R * SUB, lane);
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            acc = fmadd(v[k], xv[k], acc);
-            if (c[k] >> 15) { /* last entry of the lane's segment number kseg */
-                if (kseg - gflushed < (unsigned int)Q) {
-                    s_q[w][kseg & (Q - 1)][lane] = acc;
-                } else {
-                    store_untracked(out + (kseg * 64u + (unsigned int)lane), acc);
-                    direct |= 1u << (kseg & 31u);
-                }
-                ++kseg;
-                acc = (T)0;
-            }
-        }
-        /* every lane past group gflushed?  (the wave's last group may be short of lanes: it leaves
-         * after the loop) */
-        while (gflushed + 1 < ngroups && __builtin_amdgcn_ballot_w64(kseg > gflushed) == ~0ull)
-            write_out();
-    };
-    const int nsub = (P1 - P0) / SUB;
-    int j = 0;
-    for (; j + R <= nsub; j += R) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            sub_window(set[r], P0 + (j + r) * SUB, true);
-    }
-#pragma unroll
-    for (int r = 0; r < R - 1; ++r)
-        if (j + r < nsub) /* wave-uniform */
-            sub_window(set[r], P0 + (j + r) * SUB, false);
-    /* what is still queued: lanes without a segment in a group write nothing */
-    while (gflushed < ngroups) {
-        const T v = s_q[w][gflushed & (Q - 1)][lane];
-        if (kseg > gflushed && !((direct >> (gflushed & 31u)) & 1u))
-            store_untracked(out + (gflushed * 64u + (unsigned int)lane), v);
-        ++gflushed;
-    }
-}
-
-/* y[r] = the row's slots added in stripe order (islot < 0: nothing in that stripe); dotv as in
- * k_stripe_sum */
-template <typename T>
-__global__ void __launch_bounds__(SPMV_WG) k_lane_sum(const T *__restrict__ partial, const int *__restrict__ islot,
-                                                      T *__restrict__ y, int rows, int S,
-                                                      const T *__restrict__ dotv, T *__restrict__ dot_part)
-{
-    const int r = blockIdx.x * SPMV_WG + threadIdx.x;
-    T acc = (T)0;
-    if (r < rows) {
-        const int *ip = islot + r;
-        int s = 0;
-        for (; s + 8 <= S; s += 8) {
-            int q[8];
-            T v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                q[k] = ip[(size_t)(s + k) * rows];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                v[k] = partial[q[k] < 0 ? 0 : q[k]];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                acc = acc + (q[k] < 0 ? (T)0 : v[k]);
-        }
-        for (; s < S; ++s) {
-            const int q = ip[(size_t)s * rows];
-            const T v = partial[q < 0 ? 0 : q];
-            acc = acc + (q < 0 ? (T)0 : v);
-        }
+        for (; g < NG; ++g)
+            acc = acc + p[(size_t)g * rows];
         y[r] = acc;
     }
     if (dotv) { /* kernel-uniform */
@@ -1208,6 +1087,8 @@ void spmvk_set_tuning(int key, int value)
         g_tune_nt = value;
     else if (key == 5 && value >= 0 && value <= 8)
         g_tune_tile_k = value;
+    else if (key == 6)
+        g_tune_abl = value;
 }
 
 int spmvk_ordered(const spmv_dev_csr *m, const void *x, void *y, void *stream)
@@ -1317,113 +1198,42 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
     hipStream_t st = (hipStream_t)stream;
     if (t->rows <= 0)
         return 0;
-    const int grid = t->S * t->B;
-#define SPMV_LS2(T, WPB, R, XT, EPL)                                                                   \
-    hipLaunchKernelGGL((k_striped<T, WPB, R, XT, EPL>), dim3(grid), dim3(WPB * 64), 0, st, t->wptr,    \
-                       t->wrow, t->col, (const T *)t->val, (const T *)x, (T *)t->partial, t->rows,     \
-                       t->cols, t->B, t->W)
-#define SPMV_LS2R(T, WPB, XT, EPL)                                                                     \
-    do {                                                                                               \
-        if (g_tune_tile_k == 4)                                                                        \
-            SPMV_LS2(T, WPB, 4, XT, EPL);                                                              \
-        else if (g_tune_tile_k == 3)                                                                   \
-            SPMV_LS2(T, WPB, 3, XT, EPL);                                                              \
-        else                                                                                           \
-            SPMV_LS2(T, WPB, 2, XT, EPL);                                                              \
-    } while (0)
-    const int xt = t->xbytes; /* LDS stripe capacity the layout was built for; t->W <= xt / elem */
-    if (t->WPB == 8 && xt == 65536 && t->EPL == 4) {
-        if (t->elem == 8)
-            SPMV_LS2R(double, 8, 65536, 4);
-        else
-            SPMV_LS2R(float, 8, 65536, 4);
-    } else if (t->WPB == 8 && xt == 65536 && t->EPL == 8) {
-        if (t->elem == 8)
-            SPMV_LS2R(double, 8, 65536, 8);
-        else
-            SPMV_LS2R(float, 8, 65536, 8);
-    } else if (t->WPB == 16 && xt == 65536 && t->EPL == 4) {
-        if (t->elem == 8)
-            SPMV_LS2R(double, 16, 65536, 4);
-        else
-            SPMV_LS2R(float, 16, 65536, 4);
-    } else if (t->WPB == 16 && xt == 65536 && t->EPL == 8) {
-        if (t->elem == 8)
-            SPMV_LS2R(double, 16, 65536, 8);
-        else
-            SPMV_LS2R(float, 16, 65536, 8);
-    } else if (t->WPB == 16 && xt == 131072 && t->EPL == 8) {
-        if (t->elem == 8)
-            SPMV_LS2R(double, 16, 131072, 8);
-        else
-            SPMV_LS2R(float, 16, 131072, 8);
-    } else if (t->WPB == 16 && xt == 131072 && t->EPL == 4) {
-        if (t->elem == 8)
-            SPMV_LS2R(double, 16, 131072, 4);
-        else
-            SPMV_LS2R(float, 16, 131072, 4);
-    } else {
+    /* the one instantiated shape: 16 waves, 128 KiB of x, 4 entries per lane per sub-window, 16 accumulators */
+    if (t->WPB != SPMV_STRIPE_WPB || t->xbytes != SPMV_STRIPE_XBYTES || t->EPL != SPMV_STRIPE_EPL ||
+        t->wave_rows > SPMV_STRIPE_WAVE_ROWS || (t->NG > 1 && !t->partial))
         return (int)hipErrorInvalidValue;
-    }
+    const int nwg = t->NB * t->NG;
+    const int per = g_tune_xcd ? (nwg + 7) / 8 : 0; /* workgroups of one stripe group share an XCD's L2 for x */
+    const int grid = per ? per * 8 : nwg;
+#define SPMV_LS2(T, R)                                                                                          \
+    hipLaunchKernelGGL((k_striped<T, SPMV_STRIPE_WPB, R, SPMV_STRIPE_XBYTES, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC>), \
+                       dim3(grid), dim3(SPMV_STRIPE_WPB * 64), 0, st, t->tptr, t->rrow, t->col, (const T *)t->val, \
+                       (const T *)x, (T *)y, (T *)t->partial, (const T *)dotv, (T *)dot_part, t->rows,             \
+                       t->cols, t->S, t->NB, t->NG, t->GM, t->W, nwg, per, g_tune_abl)
+#define SPMV_LS2R(T)                                                                                            \
+    do {                                                                                                        \
+        if (g_tune_tile_k == 4)                                                                                 \
+            SPMV_LS2(T, 4);                                                                                     \
+        else if (g_tune_tile_k == 3)                                                                            \
+            SPMV_LS2(T, 3);                                                                                     \
+        else                                                                                                    \
+            SPMV_LS2(T, 2);                                                                                     \
+    } while (0)
+    if (t->elem == 8)
+        SPMV_LS2R(double);
+    else
+        SPMV_LS2R(float);
 #undef SPMV_LS2R
 #undef SPMV_LS2
-    if (t->elem == 8)
-        hipLaunchKernelGGL(k_stripe_sum<double>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
-                           (const double *)t->partial, (double *)y, t->rows, t->S, (const double *)dotv,
-                           (double *)dot_part);
-    else
-        hipLaunchKernelGGL(k_stripe_sum<float>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
-                           (const float *)t->partial, (float *)y, t->rows, t->S, (const float *)dotv,
-                           (float *)dot_part);
-    return launch_status();
-}
-
-int spmvk_lanes(const spmv_dev_lanes *t, const void *x, void *y, void *stream, const void *dotv, void *dot_part)
-{
-    hipStream_t st = (hipStream_t)stream;
-    if (t->rows <= 0)
-        return 0;
-    const int grid = t->S * t->B;
-#define SPMV_LL(T, WPB, R, XT)                                                                          \
-    hipLaunchKernelGGL((k_lanes<T, WPB, R, XT>), dim3(grid), dim3(WPB * 64), 0, st, t->wptr, t->wslot,   \
-                       t->col, (const T *)t->val, (const T *)x, (T *)t->partial, t->cols, t->B, t->W)
-#define SPMV_LLR(T, WPB, XT)                                                                            \
-    do {                                                                                                \
-        if (g_tune_tile_k == 4)                                                                         \
-            SPMV_LL(T, WPB, 4, XT);                                                                     \
-        else if (g_tune_tile_k == 3)                                                                    \
-            SPMV_LL(T, WPB, 3, XT);                                                                     \
-        else                                                                                            \
-            SPMV_LL(T, WPB, 2, XT);                                                                     \
-    } while (0)
-    if (t->WPB == 16 && t->xbytes == 131072) {
+    if (t->NG > 1) {
+        const int gs = (t->rows + SPMV_WG - 1) / SPMV_WG;
         if (t->elem == 8)
-            SPMV_LLR(double, 16, 131072);
+            hipLaunchKernelGGL(k_group_sum<double>, dim3(gs), dim3(SPMV_WG), 0, st, (const double *)t->partial,
+                               (double *)y, t->rows, t->NG, (const double *)dotv, (double *)dot_part);
         else
-            SPMV_LLR(float, 16, 131072);
-    } else if (t->WPB == 16 && t->xbytes == 65536) {
-        if (t->elem == 8)
-            SPMV_LLR(double, 16, 65536);
-        else
-            SPMV_LLR(float, 16, 65536);
-    } else if (t->WPB == 8 && t->xbytes == 65536) {
-        if (t->elem == 8)
-            SPMV_LLR(double, 8, 65536);
-        else
-            SPMV_LLR(float, 8, 65536);
-    } else {
-        return (int)hipErrorInvalidValue;
+            hipLaunchKernelGGL(k_group_sum<float>, dim3(gs), dim3(SPMV_WG), 0, st, (const float *)t->partial,
+                               (float *)y, t->rows, t->NG, (const float *)dotv, (float *)dot_part);
     }
-#undef SPMV_LLR
-#undef SPMV_LL
-    if (t->elem == 8)
-        hipLaunchKernelGGL(k_lane_sum<double>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
-                           (const double *)t->partial, t->islot, (double *)y, t->rows, t->S, (const double *)dotv,
-                           (double *)dot_part);
-    else
-        hipLaunchKernelGGL(k_lane_sum<float>, dim3((t->rows + SPMV_WG - 1) / SPMV_WG), dim3(SPMV_WG), 0, st,
-                           (const float *)t->partial, t->islot, (float *)y, t->rows, t->S, (const float *)dotv,
-                           (float *)dot_part);
     return launch_status();
 }
 

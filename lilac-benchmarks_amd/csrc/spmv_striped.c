@@ -2,35 +2,50 @@
  * csrc/spmv_striped.c -- host-side conversion of a CSR row block into the STRIPED layout used
  * by k_striped (plain C, no GPU needed).
  *
- * STRIPED is the 2-D decomposition of y = A*x: the columns are cut into stripes of W columns
- * (W * sizeof(T) = 64 KiB of x), and a workgroup owns ONE stripe for its whole life.  It copies
- * that stripe of x into LDS once and then only streams matrix entries, so the per-nonzero gather
- * of x is an LDS access (as in TILED, spmv_tiled.c) but x is staged S*B times in total instead of
- * once per row block per stripe, and there is no barrier after the staging.  The price is one
- * partial sum per (stripe, row), added up in stripe order by k_stripe_sum.
+ * STRIPED is the 2-D decomposition of y = A*x.  The columns are cut into S stripes of W columns
+ * (W * sizeof(T) <= 128 KiB of x: one stripe fits the LDS of a CU) and the rows into NB row blocks
+ * of WPB wave ranges each (a wave range = at most `wave_rows` consecutive rows, all ranges of about
+ * equal nonzero counts, the SAME cuts for every stripe).  The stripes are dealt to NG groups of
+ * consecutive stripes, and a workgroup = (stripe group g, row block rb).  It walks the stripes of its
+ * group one after the other: copy the stripe of x into LDS, then each of its WPB waves streams the
+ * entries of ITS rows that fall into that stripe -- the per-nonzero gather of x is an LDS access --
+ * and adds each row's sum for the stripe into a per-row accumulator that lives in the wave's
+ * registers across the whole group (lane l, register k <-> row 64 k + l of the wave range).  Only
+ * when the group is done does a row sum leave the CU: one partial sum per (stripe GROUP, row), or y
+ * itself when NG = 1.
+ *
+ * Why groups: with one stripe per workgroup (round 1) a row cost one partial sum per STRIPE; on NPB
+ * class D (1.5 M columns, 92 stripes, 5 nonzeros per row and stripe) writing and re-reading them was
+ * 24 % of all bytes moved.  With groups, the partial sums shrink by the group length; k_group_sum adds
+ * the NG partials of a row in group order (a second, small launch: see the note there on why not the
+ * last workgroup to arrive).
  *
  * Layout (offsets in entries):
  *
- *   stripe s   holds, row after row, the entries of every row that fall into columns
- *              [s*W, (s+1)*W), each row's entries in their original CSR order;
- *   val[]      T, packed;
- *   col[]      uint16: bits 0..14 = column - 1 - s*W, bit 15 = "last entry of its row in this
- *              stripe".  Every row owns exactly one flagged entry per stripe -- a row with no
- *              nonzero in the stripe gets a dummy (value 0, column 0, flag set) -- so a wave
- *              recovers row numbers by counting flags and needs no row pointers at all;
- *   waves      the rows of a stripe are cut into B*WPB contiguous ranges of about equal entry
- *              counts; wave (s, b, w) streams [wptr[i], wptr[i+1]), i = (s*B + b)*WPB + w, which
- *              is a whole number of sub-windows of 64*EPL entries (pads: value 0, column 0, no
- *              flag) and begins with row wrow[i];
- *   values     inside each sub-window the values are stored lane-interleaved in 16-byte units:
- *              entry e = l*EPL + i sits at (i/G)*(64*G) + l*G + i%G, G = 16/sizeof(T), so that
- *              lane l, which owns entries l*EPL.., reads them with dense 16-byte-per-lane loads
- *              (the 16-bit columns of a lane are contiguous already).
+ *   tile (g, rb, w, si)   the entries of wave range (rb, w) in stripe s = s0(g) + si, row after row,
+ *                         each row's entries in their original CSR order; a whole number of
+ *                         sub-windows of 64*EPL entries (pads: value 0, the zero column, no flag);
+ *                         a wave's tiles follow each other in memory (one linear stream per wave per
+ *                         workgroup), waves of a workgroup and workgroups (g-major) follow each other;
+ *   tptr[]                int32 [(NG*NB*WPB) * (GM + 1)]: tile starts of wave (g, rb, w), GM =
+ *                         ceil(S / NG) stripes per group at most, entry GM (and those past the
+ *                         group's last stripe) = end of the wave's stream;
+ *   rrow[]                int32 [NB*WPB + 1]: first row of every wave range;
+ *   val[]                 T, packed; inside each sub-window lane-interleaved in 16-byte units: entry
+ *                         e = l*EPL + i sits at (i/G)*(64*G) + l*G + i%G, G = 16/sizeof(T), so that
+ *                         lane l, which owns entries l*EPL.., reads them with dense 16-byte loads;
+ *   col[]                 uint16: bits 0..14 = column - 1 - s*W, bit 15 = "last entry of its row in
+ *                         this stripe".  Every row owns exactly one flagged entry per stripe -- a row
+ *                         with no nonzero in the stripe gets a filler (value 0, the zero column, flag
+ *                         set) -- so a wave recovers row numbers by counting flags and reads no row
+ *                         pointers at all.  The zero column is the last element of the kernel's LDS
+ *                         buffer, which is kept at 0: a non-finite x entry cannot reach a row that
+ *                         does not reference it.
  *
- * Summation order: inside a (row, stripe) segment a fixed tree (4-entry lane sums, then a
- * segmented wave scan), across stripes ascending.  Deterministic, but not the reference's
- * left-to-right order: results agree with native-impl.c within the reordering bound, not bit for
- * bit (TILED and ORDERED are the bit-exact plans).
+ * Summation order: inside a (row, stripe) segment a fixed tree (EPL-entry lane sums, then a segmented
+ * wave scan), across the stripes of a group ascending, across groups ascending.  Deterministic, but
+ * not the reference's left-to-right order: results agree with native-impl.c within the reordering
+ * bound, not bit for bit (TILED and ORDERED are the bit-exact plans).
  */
 #include "spmv_internal.h"
 
@@ -41,53 +56,90 @@ void spmv_striped_free(spmv_striped_host *t)
 {
     free(t->val);
     free(t->col);
-    free(t->wptr);
-    free(t->wrow);
+    free(t->tptr);
+    free(t->rrow);
     memset(t, 0, sizeof *t);
 }
 
-void spmv_striped_geometry(int rows, int cols, int elem_size, int xbytes, int wpb, int target_wgs, int epl,
-                           spmv_striped_host *t)
+void spmv_striped_default_opts(spmv_striped_opts *o)
+{
+    o->xbytes = SPMV_STRIPE_XBYTES;
+    o->wpb = SPMV_STRIPE_WPB;
+    o->target_wgs = SPMV_STRIPE_TARGET_WGS;
+    o->wave_rows = SPMV_STRIPE_WAVE_ROWS;
+    o->groups = 0;
+}
+
+void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped_opts *o, spmv_striped_host *t)
 {
     memset(t, 0, sizeof *t);
     t->elem = elem_size;
-    t->EPL = epl == 4 ? 4 : 8;
-    t->WPB = wpb;
-    int wmax = xbytes / elem_size; /* columns that fit the LDS stripe buffer */
+    t->EPL = SPMV_STRIPE_EPL;
+    t->WPB = o->wpb;
+    int wmax = o->xbytes / elem_size; /* columns that fit the LDS stripe buffer */
     if (wmax > 32768)
         wmax = 32768; /* 15 column bits */
-    /* the top 16 bytes of the buffer are not x: its last element is kept at 0 and is what the filler
-     * of an empty (row, stripe) segment multiplies with, so that a non-finite x entry cannot reach a
-     * row that does not reference it (0 * Inf = NaN) */
+    t->cap = wmax;
+    /* the top 16 bytes of the buffer are not x: its last element is kept at 0 and is what fillers and pads
+     * multiply with */
     wmax -= 16 / elem_size;
-    if (target_wgs < 1)
-        target_wgs = 1;
-    /*
-     * Fewest stripes that fit LDS (fewest partial sums per row), all of the same width, then as many row ranges per
-     * stripe as keep S * B within the target: every workgroup is resident at once, no tail round.
-     * Narrower stripes that fill the last workgroup slots were measured and lose: on a class D row
-     * block S = 125 (250 workgroups) ran 270 us against 250 us for S = 92 (184 workgroups), because
-     * every extra stripe adds a row-end marker and a partial sum per row.
-     */
+    /* fewest stripes that fit LDS, all of the same width (with full-width stripes and a remainder, the last
+     * stripe of NPB class C held 1.7 % of the nonzeros but a tenth of the workgroups) */
     int s_min = cols > 0 ? (cols + wmax - 1) / wmax : 1;
-    /* equal stripes: with full-width stripes and a remainder, the last stripe of NPB class C held
-     * 1.7 % of the nonzeros but a tenth of the workgroups */
     const int unit = 16 / elem_size; /* stripes start on 16-byte boundaries of x */
-    int best_w = cols > 0 ? ((cols + s_min - 1) / s_min + unit - 1) / unit * unit : wmax;
-    if (best_w > wmax)
-        best_w = wmax;
-    if (best_w < unit)
-        best_w = unit;
-    s_min = cols > 0 ? (cols + best_w - 1) / best_w : 1;
-    int best_s = s_min, best_b = target_wgs / s_min > 0 ? target_wgs / s_min : 1;
-    if (best_b < 1)
-        best_b = 1;
-    /* no point in more waves than rows */
-    while (best_b > 1 && (int64_t)best_b * wpb > (int64_t)rows)
-        --best_b;
-    t->W = best_w;
-    t->S = best_s;
-    t->B = best_b;
+    int w = cols > 0 ? ((cols + s_min - 1) / s_min + unit - 1) / unit * unit : wmax;
+    if (w > wmax)
+        w = wmax;
+    if (w < unit)
+        w = unit;
+    t->W = w;
+    t->S = cols > 0 ? (cols + w - 1) / w : 1;
+    /*
+     * Row blocks and stripe groups.  A wave holds at most wave_rows row accumulators, which sets the
+     * least number of row blocks; within that, as many stripe groups as keep NB * NG within the target
+     * (every workgroup resident at once: one 160-KiB workgroup per CU), because fewer stripes per
+     * workgroup mean fewer re-stagings of x and longer uninterrupted streams, and the partial sums
+     * that more groups cost are few: class C 10 groups x 25 row blocks (12 MB of partials beside a
+     * 373 MB stream), a class D row block of 187 500 rows 21 x 12 (4-5 stripes per group), all of
+     * class D 2 x 128.
+     */
+    const int target = o->target_wgs < 1 ? 1 : o->target_wgs;
+    const int64_t per_block = (int64_t)o->wpb * o->wave_rows;
+    int nb_min = rows > 0 ? (int)((rows + per_block - 1) / per_block) : 1;
+    int ng = o->groups > 0 ? o->groups : target / nb_min;
+    if (ng < 1)
+        ng = 1;
+    if (ng > t->S)
+        ng = t->S;
+    int nb = target / ng;
+    if (nb < nb_min)
+        nb = nb_min;
+    while (nb > nb_min && (int64_t)nb * o->wpb > (int64_t)rows) /* no point in more waves than rows */
+        --nb;
+    t->NB = nb;
+    t->NG = ng;
+    t->GM = (t->S + ng - 1) / ng;
+    t->n_ranges = nb * o->wpb;
+}
+
+/* exact c / W for 0 <= c < 2^31 without a hardware divide per nonzero */
+typedef struct fastdiv {
+    uint64_t m;
+    uint32_t w;
+} fastdiv;
+static fastdiv fastdiv_make(int w)
+{
+    fastdiv d;
+    d.w = (uint32_t)w;
+    d.m = ((uint64_t)1 << 40) / (uint64_t)w + 1;
+    return d;
+}
+static inline uint32_t fastdiv_do(fastdiv d, uint32_t c)
+{
+    uint32_t q = (uint32_t)(((uint64_t)c * d.m) >> 40); /* exact or one too large */
+    if ((uint64_t)q * d.w > c)
+        --q;
+    return q;
 }
 
 /* ---- the conversion, in passes that split over host threads --------------------------------- */
@@ -95,125 +147,158 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, int xbytes, int wp
 typedef struct build_ctx {
     const void *a;
     const int *rowstr, *colidx;
-    int r0, rows, cols, elem, S, W, B, WPB, EPL, G;
-    int cap;         /* elements of the kernel's LDS buffer: its last one is the fillers' zero */
+    int r0, rows, cols, elem, S, W, NB, NG, GM, WPB, EPL, G, cap;
     int64_t SUB;
-    int32_t *cnt;    /* [S][rows] entries of row r in stripe s                               */
-    int32_t *start;  /* [S][rows] position of the segment's first entry, relative to its stripe */
-    int64_t *sbase;  /* [S+1]     first position of each stripe                               */
-    int64_t *sdummy; /* [S]       fillers per stripe                                           */
-    int32_t *wlen;   /* [nw]      wave run lengths (whole sub-windows), then absolute via wptr */
+    fastdiv div;
+    int64_t *tsize;   /* [n_ranges][S] padded tile sizes */
+    int64_t *rfill;   /* [n_ranges] fillers */
+    int *sg, *ssi;    /* [S] group of a stripe and its index inside the group */
     spmv_striped_host *t;
-    volatile int bad; /* a column outside [1, cols] was seen */
+    volatile int bad; /* 1: a column outside [1, cols]; 2: out of memory */
 } build_ctx;
 
-/* pass 1, over rows: count the entries per (stripe, row) */
+/* pass 1, over wave ranges: entries (fillers included) per (range, stripe) */
 static void pass_count(int64_t lo, int64_t hi, void *vc)
 {
     build_ctx *c = (build_ctx *)vc;
-    for (int64_t r = lo; r < hi; ++r)
-        for (int j = c->rowstr[c->r0 + r] - 1; j < c->rowstr[c->r0 + r + 1] - 1; ++j) {
-            const int col = c->colidx[j] - 1;
-            if (col < 0 || col >= c->cols) {
-                c->bad = 1;
-                return;
-            }
-            c->cnt[(size_t)(col / c->W) * c->rows + r]++;
-        }
-}
-
-/* pass 2, over stripes: cut the rows of a stripe into B*WPB ranges of about equal entry counts and
- * place every segment relative to the stripe's start (every wave streams whole sub-windows) */
-static void pass_layout(int64_t lo, int64_t hi, void *vc)
-{
-    build_ctx *c = (build_ctx *)vc;
-    const int rows = c->rows, parts = c->B * c->WPB;
-    for (int64_t s = lo; s < hi; ++s) {
-        const int32_t *cs = c->cnt + (size_t)s * rows;
-        int32_t *st = c->start + (size_t)s * rows;
-        int64_t stripe_entries = 0, dummies = 0;
-        for (int r = 0; r < rows; ++r)
-            stripe_entries += cs[r] > 0 ? cs[r] : 1;
-        int r = 0;
-        int64_t done = 0, total = 0;
-        for (int p = 0; p < parts; ++p) {
-            const int wi = (int)s * parts + p;
-            const int64_t wave_begin = total;
-            c->t->wrow[wi] = r;
-            const int64_t target = stripe_entries * (p + 1) / parts;
-            /* leave at least one row for every remaining part when possible */
-            while (r < rows && (done < target || p == parts - 1)) {
-                if (p < parts - 1 && rows - r <= parts - 1 - p)
-                    break;
-                const int n = cs[r] > 0 ? cs[r] : 1;
-                dummies += cs[r] == 0;
-                st[r] = (int32_t)total;
-                total += n;
-                done += n;
-                ++r;
-            }
-            total = (total + c->SUB - 1) / c->SUB * c->SUB;
-            c->wlen[wi] = (int32_t)(total - wave_begin);
-        }
-        c->sbase[s + 1] = total; /* turned into a running sum by the caller */
-        c->sdummy[s] = dummies;
-    }
-}
-
-/* pass 3, over rows: scatter in CSR order; a row's segments are touched by its own thread only */
-static void pass_scatter(int64_t lo, int64_t hi, void *vc)
-{
-    build_ctx *c = (build_ctx *)vc;
-    const int rows = c->rows, S = c->S, W = c->W, EPL = c->EPL, G = c->G;
-    const int64_t SUB = c->SUB;
-    int32_t *fill = (int32_t *)malloc((size_t)S * sizeof(int32_t));
-    if (!fill) {
+    const int S = c->S;
+    int32_t *stamp = (int32_t *)malloc((size_t)S * sizeof(int32_t));
+    if (!stamp) {
         c->bad = 2;
         return;
     }
-    uint16_t *tcol = c->t->col;
-    for (int64_t r = lo; r < hi; ++r) {
-        const int jb = c->rowstr[c->r0 + r] - 1, je = c->rowstr[c->r0 + r + 1] - 1;
-        if (jb == je)
-            continue;
-        memset(fill, 0, (size_t)S * sizeof(int32_t));
-        for (int j = jb; j < je; ++j) {
-            const int col = c->colidx[j] - 1;
-            const int s = col / W;
-            const size_t k = (size_t)s * rows + r;
-            const int64_t dst = c->sbase[s] + c->start[k] + fill[s]++;
-            uint16_t cc = (uint16_t)(col - s * W);
-            if (fill[s] == c->cnt[k])
-                cc |= 0x8000u; /* last entry of this row in this stripe */
-            tcol[dst] = cc;
-            /* values: lane-interleaved in 16-byte units inside each sub-window, so that lane l
-             * (entries l*EPL .. l*EPL+EPL-1) fetches them with dense 16-byte-per-lane loads */
-            const int64_t blk = dst / SUB * SUB, rr = dst % SUB;
-            const int64_t l = rr / EPL, i = rr % EPL;
-            const int64_t vdst = blk + (i / G) * (64 * G) + l * G + (i % G);
-            if (c->elem == 8)
-                ((double *)c->t->val)[vdst] = ((const double *)c->a)[j];
-            else
-                ((float *)c->t->val)[vdst] = ((const float *)c->a)[j];
+    for (int64_t u = lo; u < hi; ++u) {
+        int64_t *cnt = c->tsize + (size_t)u * S;
+        memset(cnt, 0, (size_t)S * sizeof(int64_t));
+        for (int s = 0; s < S; ++s)
+            stamp[s] = -1;
+        int64_t fillers = 0;
+        for (int r = c->t->rrow[u]; r < c->t->rrow[u + 1]; ++r) {
+            int distinct = 0;
+            for (int j = c->rowstr[c->r0 + r] - 1; j < c->rowstr[c->r0 + r + 1] - 1; ++j) {
+                const int col = c->colidx[j] - 1;
+                if (col < 0 || col >= c->cols) {
+                    c->bad = 1;
+                    free(stamp);
+                    return;
+                }
+                const uint32_t s = fastdiv_do(c->div, (uint32_t)col);
+                cnt[s]++;
+                if (stamp[s] != r)
+                    stamp[s] = r, ++distinct;
+            }
+            if (distinct < S) {
+                for (int s = 0; s < S; ++s)
+                    cnt[s] += stamp[s] != r;
+                fillers += S - distinct;
+            }
         }
+        c->rfill[u] = fillers;
+        for (int s = 0; s < S; ++s)
+            cnt[s] = (cnt[s] + c->SUB - 1) / c->SUB * c->SUB;
     }
-    free(fill);
+    free(stamp);
 }
 
-/* pass 4, over stripes: the filler of an empty segment is a flag-only entry: value 0, and as its
- * column the last element of the LDS buffer, which the kernel keeps at 0 (spmv_striped_geometry) */
-static void pass_fillers(int64_t lo, int64_t hi, void *vc)
+static inline int64_t val_slot(const build_ctx *c, int64_t p)
+{
+    /* values: lane-interleaved in 16-byte units inside each sub-window, so that lane l (entries
+     * l*EPL .. l*EPL+EPL-1) fetches them with dense 16-byte-per-lane loads */
+    const int64_t blk = p / c->SUB * c->SUB, rr = p % c->SUB;
+    const int64_t l = rr / c->EPL, i = rr % c->EPL;
+    return blk + (i / c->G) * (64 * c->G) + l * c->G + (i % c->G);
+}
+
+/* pass 2, over wave ranges: scatter in CSR order; a range's tiles are touched by its own thread only */
+static void pass_scatter(int64_t lo, int64_t hi, void *vc)
 {
     build_ctx *c = (build_ctx *)vc;
-    for (int64_t s = lo; s < hi; ++s) {
-        if (c->sdummy[s] == 0)
-            continue;
-        const int32_t *cs = c->cnt + (size_t)s * c->rows;
-        const int32_t *st = c->start + (size_t)s * c->rows;
-        for (int r = 0; r < c->rows; ++r)
-            if (cs[r] == 0)
-                c->t->col[c->sbase[s] + st[r]] = (uint16_t)(0x8000u | (unsigned)(c->cap - 1));
+    const int S = c->S, W = c->W;
+    int32_t *stamp = (int32_t *)malloc((size_t)S * sizeof(int32_t));
+    int64_t *pos = (int64_t *)malloc((size_t)S * sizeof(int64_t));
+    int64_t *last = (int64_t *)malloc((size_t)S * sizeof(int64_t));
+    if (!stamp || !pos || !last) {
+        c->bad = 2;
+        free(stamp), free(pos), free(last);
+        return;
     }
+    uint16_t *tcol = c->t->col;
+    const uint16_t zero_col = (uint16_t)(c->cap - 1);
+    const int nr = c->t->n_ranges;
+    for (int64_t u = lo; u < hi; ++u) {
+        for (int s = 0; s < S; ++s) {
+            pos[s] = c->t->tptr[((size_t)c->sg[s] * nr + (size_t)u) * ((size_t)c->GM + 1) + c->ssi[s]];
+            stamp[s] = -1;
+        }
+        for (int r = c->t->rrow[u]; r < c->t->rrow[u + 1]; ++r) {
+            int distinct = 0;
+            for (int j = c->rowstr[c->r0 + r] - 1; j < c->rowstr[c->r0 + r + 1] - 1; ++j) {
+                const int col = c->colidx[j] - 1;
+                const uint32_t s = fastdiv_do(c->div, (uint32_t)col);
+                const int64_t p = pos[s]++;
+                tcol[p] = (uint16_t)(col - (int)s * W);
+                const int64_t v = val_slot(c, p);
+                if (c->elem == 8)
+                    ((double *)c->t->val)[v] = ((const double *)c->a)[j];
+                else
+                    ((float *)c->t->val)[v] = ((const float *)c->a)[j];
+                last[s] = p;
+                if (stamp[s] != r)
+                    stamp[s] = r, ++distinct;
+            }
+            if (distinct == S) {
+                for (int s = 0; s < S; ++s)
+                    tcol[last[s]] |= 0x8000u; /* last entry of this row in this stripe */
+            } else {
+                for (int s = 0; s < S; ++s)
+                    if (stamp[s] == r)
+                        tcol[last[s]] |= 0x8000u;
+                    else /* the filler of an empty segment: flag only, value 0 (calloc), times the zero column */
+                        tcol[pos[s]++] = (uint16_t)(0x8000u | zero_col);
+            }
+        }
+        /* the rest of every tile is padding: value 0 (calloc) times the zero column, no flag */
+        for (int s = 0; s < S; ++s) {
+            const int64_t end = c->t->tptr[((size_t)c->sg[s] * nr + (size_t)u) * ((size_t)c->GM + 1) + c->ssi[s] + 1];
+            for (int64_t p = pos[s]; p < end; ++p)
+                tcol[p] = zero_col;
+        }
+    }
+    free(stamp), free(pos), free(last);
+}
+
+/*
+ * The wave ranges: NB*WPB runs of consecutive rows of about equal weight (nonzeros + 1), none longer
+ * than wave_rows rows, every one non-empty while rows last.
+ */
+static void cut_rows(const int *rowstr, int r0, int rows, int n_ranges, int wave_rows, int32_t *rrow)
+{
+    int64_t remaining = (int64_t)rowstr[r0 + rows] - rowstr[r0] + rows;
+    int r = 0;
+    for (int i = 0; i < n_ranges; ++i) {
+        rrow[i] = r;
+        const int left = n_ranges - i;
+        const int64_t target = (remaining + left - 1) / left;
+        int64_t acc = 0;
+        while (r < rows) {
+            const int64_t w = (int64_t)rowstr[r0 + r + 1] - rowstr[r0 + r] + 1;
+            const int taken = r - rrow[i];
+            /* the ranges after this one hold (left - 1) * wave_rows rows at most */
+            const int must = (int64_t)(rows - r) > (int64_t)(left - 1) * wave_rows;
+            if (!must) {
+                if (taken >= wave_rows)
+                    break;
+                if (taken >= 1 && rows - r <= left - 1)
+                    break; /* leave a row for every range that follows */
+                if (taken >= 1 && acc + w / 2 >= target)
+                    break;
+            }
+            acc += w;
+            ++r;
+        }
+        remaining -= acc;
+    }
+    rrow[n_ranges] = rows;
 }
 
 /*
@@ -222,87 +307,105 @@ static void pass_fillers(int64_t lo, int64_t hi, void *vc)
  * The result does not depend on the number of threads (SPMV_HIP_BUILD_THREADS).
  */
 int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,
-                       int elem_size, int xbytes, int wpb, int target_wgs, int epl, spmv_striped_host *t)
+                       int elem_size, const spmv_striped_opts *opts, spmv_striped_host *t)
 {
     const int rows = r1 - r0;
-    spmv_striped_geometry(rows, cols, elem_size, xbytes, wpb, target_wgs, epl, t);
+    spmv_striped_opts dflt;
+    if (!opts) {
+        spmv_striped_default_opts(&dflt);
+        opts = &dflt;
+    }
+    spmv_striped_geometry(rows, cols, elem_size, opts, t);
     const int S = t->S;
-    if (rows <= 0 || (int64_t)S * rows > ((int64_t)1 << 28))
+    if (rows <= 0 || opts->wave_rows < 64 || opts->wave_rows % 64 || S > 32768 /* fastdiv_do */ ||
+        (int64_t)t->n_ranges * S > ((int64_t)1 << 26))
         return -2;
     const int64_t nnz = (int64_t)rowstr[r1] - rowstr[r0];
-    const int nw = S * t->B * t->WPB;
+    const int nr = t->n_ranges;
 
     build_ctx c;
     memset(&c, 0, sizeof c);
     c.a = a, c.rowstr = rowstr, c.colidx = colidx;
     c.r0 = r0, c.rows = rows, c.cols = cols, c.elem = elem_size;
-    c.S = S, c.W = t->W, c.B = t->B, c.WPB = t->WPB, c.EPL = t->EPL;
-    c.G = 16 / elem_size;        /* values per 16-byte unit */
-    c.cap = xbytes / elem_size > 32768 ? 32768 : xbytes / elem_size;
+    c.S = S, c.W = t->W, c.NB = t->NB, c.NG = t->NG, c.GM = t->GM, c.WPB = t->WPB, c.EPL = t->EPL;
+    c.G = 16 / elem_size; /* values per 16-byte unit */
+    c.cap = t->cap;
     c.SUB = 64 * (int64_t)t->EPL; /* entries per sub-window */
+    c.div = fastdiv_make(t->W);
     c.t = t;
     int rc = -1;
-    c.cnt = (int32_t *)calloc((size_t)S * rows, sizeof(int32_t));
-    c.start = (int32_t *)malloc((size_t)S * rows * sizeof(int32_t));
-    c.sbase = (int64_t *)calloc((size_t)S + 1, sizeof(int64_t));
-    c.sdummy = (int64_t *)calloc((size_t)S, sizeof(int64_t));
-    c.wlen = (int32_t *)calloc((size_t)nw + 1, sizeof(int32_t));
-    t->n_waves = nw;
-    t->wptr = (int32_t *)calloc((size_t)nw + 1, sizeof(int32_t));
-    t->wrow = (int32_t *)calloc((size_t)nw + 1, sizeof(int32_t));
-    if (!c.cnt || !c.start || !c.sbase || !c.sdummy || !c.wlen || !t->wptr || !t->wrow)
+    c.tsize = (int64_t *)malloc((size_t)nr * S * sizeof(int64_t));
+    c.rfill = (int64_t *)calloc((size_t)nr, sizeof(int64_t));
+    c.sg = (int *)malloc((size_t)S * sizeof(int));
+    c.ssi = (int *)malloc((size_t)S * sizeof(int));
+    t->rrow = (int32_t *)calloc((size_t)nr + 1, sizeof(int32_t));
+    const size_t ntp = (size_t)t->NG * nr * ((size_t)t->GM + 1);
+    t->tptr = (int32_t *)calloc(ntp, sizeof(int32_t));
+    if (!c.tsize || !c.rfill || !c.sg || !c.ssi || !t->rrow || !t->tptr)
         goto out;
+    for (int g = 0; g < t->NG; ++g)
+        for (int s = (int)((int64_t)g * S / t->NG); s < (int)((int64_t)(g + 1) * S / t->NG); ++s)
+            c.sg[s] = g, c.ssi[s] = s - (int)((int64_t)g * S / t->NG);
 
-    spmv_parallel_for(rows, 4096, pass_count, &c);
+    cut_rows(rowstr, r0, rows, nr, opts->wave_rows, t->rrow);
+    spmv_parallel_for(nr, 1, pass_count, &c);
     if (c.bad) {
-        rc = -2;
+        rc = c.bad == 1 ? -2 : -1;
         goto out;
     }
-    spmv_parallel_for(S, 1, pass_layout, &c);
 
-    int64_t total = 0, dummies = 0;
-    for (int s = 0; s < S; ++s) {
-        const int64_t len = c.sbase[s + 1];
-        c.sbase[s] = total;
-        total += len;
-        dummies += c.sdummy[s];
-    }
-    c.sbase[S] = total;
-    if (total > 0x7fffffff - 65536) {
-        rc = -2;
-        goto out;
-    }
+    /* tile starts in stream order: stripe group, row block, wave, stripe of the group */
     {
-        int64_t pos = 0;
-        for (int wi = 0; wi < nw; ++wi) {
-            t->wptr[wi] = (int32_t)pos;
-            pos += c.wlen[wi];
+        int64_t total = 0, fillers = 0, longest = 0, ntiles = 0;
+        for (int u = 0; u < nr; ++u)
+            fillers += c.rfill[u];
+        for (int g = 0; g < t->NG; ++g) {
+            const int s0 = (int)((int64_t)g * S / t->NG), s1 = (int)((int64_t)(g + 1) * S / t->NG);
+            for (int u = 0; u < nr; ++u) { /* u = rb * WPB + w */
+                int32_t *tp = t->tptr + ((size_t)g * nr + u) * ((size_t)t->GM + 1);
+                for (int si = 0; si <= t->GM; ++si) {
+                    if (total > 0x7fffffff - 65536) {
+                        rc = -2;
+                        goto out;
+                    }
+                    tp[si] = (int32_t)total;
+                    if (s0 + si < s1) {
+                        const int64_t len = c.tsize[(size_t)u * S + s0 + si];
+                        total += len;
+                        longest = len > longest ? len : longest;
+                        ++ntiles;
+                    }
+                }
+            }
         }
-        t->wptr[nw] = (int32_t)pos; /* == total */
-        t->wrow[nw] = rows;
-    }
-    t->n_packed = total;
-    t->n_dummies = dummies;
-    if (dummies * 8 > nnz) { /* more than 1/8 of the stream would be filler: the matrix is too
-                                sparse per stripe for this plan */
-        rc = -2;
-        goto out;
+        t->n_packed = total;
+        t->n_dummies = fillers;
+        t->max_tile = longest;
+        if (fillers * 8 > nnz) { /* more than 1/8 of the stream would be filler: the matrix is too sparse per
+                                    stripe for this plan */
+            rc = -2;
+            goto out;
+        }
+        /* a (row, stripe) segment is never split between waves: one dense row makes its tile many times longer
+         * than the rest, and every wave of its workgroup waits for it at the stripe's end */
+        t->skewed = longest * ntiles > 2 * total + c.SUB * ntiles;
     }
 
     {
-        const size_t n_alloc = (size_t)total + SPMV_TILE_PAD;
+        const size_t n_alloc = (size_t)t->n_packed + SPMV_TILE_PAD;
         t->val = calloc(n_alloc, (size_t)elem_size);
-        t->col = (uint16_t *)calloc(n_alloc, sizeof(uint16_t));
+        t->col = (uint16_t *)malloc(n_alloc * sizeof(uint16_t));
         if (!t->val || !t->col)
             goto out;
+        for (size_t i = (size_t)t->n_packed; i < n_alloc; ++i) /* the look-ahead past the last tile: pads too */
+            t->col[i] = (uint16_t)(c.cap - 1);
     }
-    spmv_parallel_for(rows, 1024, pass_scatter, &c);
+    spmv_parallel_for(nr, 1, pass_scatter, &c);
     if (c.bad)
         goto out;
-    spmv_parallel_for(S, 1, pass_fillers, &c);
     rc = 0;
 out:
-    free(c.cnt), free(c.start), free(c.sbase), free(c.sdummy), free(c.wlen);
+    free(c.tsize), free(c.rfill), free(c.sg), free(c.ssi);
     if (rc != 0)
         spmv_striped_free(t);
     return rc;

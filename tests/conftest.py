@@ -41,7 +41,7 @@ def build_planlib():
     return out
 
 
-PLAN_SOURCES = ("spmv_plan.c", "spmv_striped.c", "spmv_lanes.c", "spmv_tiled.c")
+PLAN_SOURCES = ("spmv_plan.c", "spmv_striped.c", "spmv_tiled.c")
 
 
 @pytest.fixture(scope="session")

@@ -62,7 +62,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
             try:
                 m.set_plan(plan, param)
             except RuntimeError as e:
-                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED, pkg.PLAN_LANES) and "not representable" in str(e):
+                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED) and "not representable" in str(e):
                     continue  # a chunk above 65535 entries: AUTO falls back to STREAM for such matrices
                 raise
             y = m.spmv_host(x)
@@ -76,7 +76,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
 
 
 def all_plans(pkg):
-    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0), (pkg.PLAN_LANES, 0)]
+    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0)]
     P += [(pkg.PLAN_VECTOR, l) for l in (1, 2, 4, 8, 16, 32, 64)]
     return P
 
@@ -127,6 +127,49 @@ def test_all_plans_on_benchmark_shapes(pkg, backend, oracle, dtype):
     for name, (rs, ci, a) in cases.items():
         x = rng.standard_normal(int(ci.max())).astype(dtype)
         check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, all_plans(pkg), name)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_striped_geometries(pkg, backend, oracle, dtype):
+    """k_striped under every shape of its 2-D decomposition: one stripe group (a workgroup walks all stripes,
+    no partial sums), several (the last wave to arrive adds the groups' partials), one per stripe; narrow wave
+    ranges (many row blocks, more workgroups than CUs) and wide ones; results within the reordering bound and
+    the same bits on every repetition (the arrival order of the groups must not matter)."""
+    rng = np.random.default_rng(23)
+    cases = {
+        "wide_40_stripes": matgen.random_csr(35, 3000, 600000, 90, dtype, spread=0.3),
+        "npb_like": matgen.npb_like(36, 20000, 200, dtype),
+        "tiny_rows": matgen.random_csr(37, 60000, 50000, 4, dtype, empty_frac=0.3, spread=0.8),
+    }
+    try:
+        for name, (rs, ci, a) in cases.items():
+            rows = rs.size - 1
+            x = rng.standard_normal(int(ci.max())).astype(dtype)
+            y_ref = oracle.spmv(a, x, rs, ci, rows)
+            absum = oracle.absum(a, x, rs, ci, rows)
+            for groups, wave_rows, wgs in [(0, 1024, 256), (1, 1024, 256), (2, 256, 256), (3, 64, 40), (1000, 1024, 256),
+                                           (4, 64, 2000)]:
+                backend.set_tuning(11, groups)
+                backend.set_tuning(12, wave_rows)
+                backend.set_tuning(9, wgs)
+                m = backend.matrix(a, rs, ci, rows)
+                try:
+                    try:
+                        m.set_plan(pkg.PLAN_STRIPED, 0)
+                    except RuntimeError as e:
+                        assert "not representable" in str(e)
+                        continue
+                    tag = "%s groups=%d wave_rows=%d wgs=%d" % (name, groups, wave_rows, wgs)
+                    y = m.spmv_host(x)
+                    assert_close_rows(y, y_ref, absum, np.diff(rs), dtype, tag)
+                    for _ in range(3):
+                        assert np.array_equal(bits(m.spmv_host(x)), bits(y)), tag
+                finally:
+                    m.close()
+    finally:
+        backend.set_tuning(11, 0)
+        backend.set_tuning(12, 1024)
+        backend.set_tuning(9, 256)
 
 
 def test_rowstr_not_starting_at_one(backend, oracle):
@@ -395,7 +438,6 @@ print("OK" if ok else "MISMATCH", s["uploads"], s["calls"], inf["plan"], inf["ro
     ({"SPMV_HIP_PIN": "pageable", "SPMV_HIP_PLAN": "vector:32"}, 2, False),
     ({"SPMV_HIP_ZEROCOPY": "0"}, 2, False),                   # small vectors through the DMA path as well
     ({"SPMV_HIP_ZEROCOPY": "0", "SPMV_HIP_PIN": "staging", "SPMV_HIP_PLAN": "striped"}, 2, False),
-    ({"SPMV_HIP_PLAN": "lanes", "SPMV_HIP_BUILD_THREADS": "3"}, 2, False),
 ])
 def test_abi_policies_in_a_fresh_process(env, uploads, exact):
     code = ABI_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__), exact="True" if exact else "False")
@@ -426,8 +468,7 @@ def test_class_c_full_size(pkg, backend, oracle):
         assert inf["algorithmic_bytes"] == 436452700
         results = {}
         for plan, param in [(pkg.PLAN_AUTO, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_VECTOR, 64), (pkg.PLAN_VECTOR, 32),
-                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0),
-                            (pkg.PLAN_LANES, 0)]:
+                            (pkg.PLAN_BINNED, 0), (pkg.PLAN_ORDERED, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0)]:
             dm.set_plan(plan, param)
             y = dm.spmv_host(x)
             results[(plan, param)] = y
@@ -766,7 +807,7 @@ def test_class_c_full_size_fp32(pkg, backend, oracle):
     lens = np.diff(m.rowstr)
     dm = backend.matrix(a, m.rowstr, m.colidx, m.rows)
     try:
-        for plan in (pkg.PLAN_AUTO, pkg.PLAN_STRIPED, pkg.PLAN_LANES, pkg.PLAN_TILED, pkg.PLAN_STREAM, pkg.PLAN_ORDERED):
+        for plan in (pkg.PLAN_AUTO, pkg.PLAN_STRIPED, pkg.PLAN_TILED, pkg.PLAN_STREAM, pkg.PLAN_ORDERED):
             dm.set_plan(plan, 0)
             y = dm.spmv_host(x)
             if plan in (pkg.PLAN_TILED, pkg.PLAN_ORDERED):

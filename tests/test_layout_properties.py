@@ -8,7 +8,7 @@ from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
 import matgen
-from test_plan import lanes_emulate, striped_emulate, tiled_emulate
+from test_plan import striped_emulate, tiled_emulate
 
 
 @pytest.fixture(scope="module")
@@ -79,16 +79,6 @@ def test_striped_layout_on_any_shape(lib, shape):
         return
     x = np.random.default_rng(seed + 1).standard_normal(int(ci.max()))
     check(striped_emulate(lib, rs, ci, a, x), rs, ci, a, x, 8)
-
-
-@settings(**COMMON)
-@given(csr_shapes())
-def test_lanes_layout_on_any_shape(lib, shape):
-    rs, ci, a, seed = shape
-    if ci.size == 0:
-        return
-    x = np.random.default_rng(seed + 2).standard_normal(int(ci.max()))
-    check(lanes_emulate(lib, rs, ci, a, x), rs, ci, a, x, 8)
 
 
 @settings(**COMMON)

@@ -228,33 +228,52 @@ def test_tiled_rejects_unrepresentable_chunks(lib):
 
 class StripedHost(ctypes.Structure):
     _fields_ = [("elem", ctypes.c_int), ("W", ctypes.c_int), ("S", ctypes.c_int), ("WPB", ctypes.c_int),
-                ("B", ctypes.c_int), ("n_waves", ctypes.c_int), ("EPL", ctypes.c_int), ("n_packed", ctypes.c_int64),
-                ("n_dummies", ctypes.c_int64), ("val", ctypes.c_void_p), ("col", ctypes.POINTER(ctypes.c_uint16)),
-                ("wptr", ctypes.POINTER(ctypes.c_int32)), ("wrow", ctypes.POINTER(ctypes.c_int32))]
+                ("EPL", ctypes.c_int), ("NB", ctypes.c_int), ("NG", ctypes.c_int), ("GM", ctypes.c_int),
+                ("n_ranges", ctypes.c_int), ("cap", ctypes.c_int), ("skewed", ctypes.c_int),
+                ("n_packed", ctypes.c_int64), ("n_dummies", ctypes.c_int64), ("max_tile", ctypes.c_int64),
+                ("val", ctypes.c_void_p), ("col", ctypes.POINTER(ctypes.c_uint16)),
+                ("tptr", ctypes.POINTER(ctypes.c_int32)), ("rrow", ctypes.POINTER(ctypes.c_int32))]
 
 
-def striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6, epl=4):
-    """Runs csrc/spmv_striped.c, checks the invariants k_striped relies on, and evaluates the layout
-    on the CPU: per wave, rows are recovered by counting row-end flags."""
+class StripedOpts(ctypes.Structure):
+    _fields_ = [("xbytes", ctypes.c_int), ("wpb", ctypes.c_int), ("target_wgs", ctypes.c_int),
+                ("wave_rows", ctypes.c_int), ("groups", ctypes.c_int)]
+
+
+def striped_build(lib, rs, ci, a, xbytes=65536, wpb=8, wgs=6, wave_rows=128, groups=0):
     rows = rs.size - 1
     cols = int(ci.max()) if ci.size else 0
     t = StripedHost()
+    o = StripedOpts(xbytes, wpb, wgs, wave_rows, groups)
     lib.spmv_striped_build.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                       ctypes.c_int, ctypes.POINTER(StripedHost)]
+                                       ctypes.c_int, ctypes.c_int, ctypes.POINTER(StripedOpts), ctypes.POINTER(StripedHost)]
     rc = lib.spmv_striped_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, rows, cols, a.dtype.itemsize,
-                                xbytes, wpb, wgs, epl, ctypes.byref(t))
+                                ctypes.byref(o), ctypes.byref(t))
+    return rc, t
+
+
+def striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6, wave_rows=128, groups=0):
+    """Runs csrc/spmv_striped.c, checks the invariants k_striped relies on, and evaluates the layout on the CPU
+    the way the kernel walks it: workgroup (stripe group, row block), wave, stripe after stripe of the group; rows
+    are recovered by counting row-end flags, row sums accumulate across the stripes of a group, the groups'
+    partial sums are added in group order."""
+    rows = rs.size - 1
+    rc, t = striped_build(lib, rs, ci, a, xbytes, wpb, wgs, wave_rows, groups)
     if rc != 0:
         return rc, None
-    nw = t.n_waves
-    assert nw == t.S * t.B * t.WPB
-    wptr = np.ctypeslib.as_array(t.wptr, (nw + 1,)).astype(np.int64)
-    wrow = np.ctypeslib.as_array(t.wrow, (nw + 1,)).astype(np.int64)
+    nr = t.n_ranges
+    assert nr == t.NB * t.WPB and t.GM == -(-t.S // t.NG) and 1 <= t.NG <= t.S
+    ntp = t.NG * nr * (t.GM + 1)
+    tptr = np.ctypeslib.as_array(t.tptr, (ntp,)).astype(np.int64).reshape(t.NG, nr, t.GM + 1)
+    rrow = np.ctypeslib.as_array(t.rrow, (nr + 1,)).astype(np.int64)
     col = np.ctypeslib.as_array(t.col, (t.n_packed + 1,)).astype(np.int64)
     ctype = ctypes.c_double if a.dtype == np.float64 else ctypes.c_float
     val = np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctype)), (t.n_packed + 1,))
     sub = 64 * t.EPL
-    assert np.all(wptr % sub == 0) and np.all(np.diff(wptr) >= 0)
+    assert rrow[0] == 0 and rrow[-1] == rows and np.all(np.diff(rrow) >= 0) and np.all(np.diff(rrow) <= wave_rows)
+    assert np.all(tptr % sub == 0) and np.all(np.diff(tptr.ravel()) >= 0) and tptr.ravel()[-1] == t.n_packed
+    if rows >= nr:
+        assert np.all(np.diff(rrow) >= 1)  # no idle wave while rows last
     # undo the lane interleave of the values inside each sub-window
     G = 16 // a.dtype.itemsize
     e = np.arange(t.n_packed, dtype=np.int64)
@@ -263,36 +282,45 @@ def striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6, epl=4):
     val = val[:t.n_packed][phys]
     flags = col[:t.n_packed] >> 15
     assert flags.sum() == t.S * rows  # exactly one row end per (stripe, row)
-    partial = np.zeros((t.S, rows), a.dtype)
-    per = t.B * t.WPB
-    for wi in range(nw):
-        s = wi // per
-        row = int(wrow[wi])
-        if wi % per == 0:
-            assert row == 0
-        run = a.dtype.type(0)
-        for q in range(int(wptr[wi]), int(wptr[wi + 1])):
-            c = int(col[q])
-            lc = c & 0x7fff
-            if lc >= t.W:  # a filler: it multiplies with the zeroed last element of the LDS buffer, never with x
-                assert lc == min(xbytes // a.dtype.itemsize, 32768) - 1 and val[q] == 0 and c >> 15
-                xv = a.dtype.type(0)
-            elif s * t.W + lc < x.size:
-                xv = x[s * t.W + lc]
-            else:  # padding of the wave's run (value 0, column 0 of a stripe that ends early)
-                assert val[q] == 0
-                xv = a.dtype.type(0)
-            run = run + val[q] * xv
-            if c >> 15:
-                partial[s, row] = run
-                row += 1
+    zero_col = min(xbytes // a.dtype.itemsize, 32768) - 1
+    assert t.cap - 1 == zero_col and t.W <= zero_col
+    partial = np.zeros((t.NG, rows), a.dtype)
+    n_fill = 0
+    for g in range(t.NG):
+        s0, s1 = g * t.S // t.NG, (g + 1) * t.S // t.NG
+        for u in range(nr):
+            nrows = int(rrow[u + 1] - rrow[u])
+            acc = np.zeros(nrows, a.dtype)
+            for si in range(t.GM + 1):
+                if s0 + si >= s1:
+                    assert tptr[g, u, si] == tptr[g, u, min(s1 - s0, t.GM)]  # past the group's last stripe: the end
+                    continue
+                s = s0 + si
+                row = 0
                 run = a.dtype.type(0)
-        nxt = int(wrow[wi + 1]) if (wi + 1) % per else rows
-        assert row == nxt, (wi, row, nxt)
+                for q in range(int(tptr[g, u, si]), int(tptr[g, u, si + 1])):
+                    c = int(col[q])
+                    lc = c & 0x7fff
+                    if lc >= t.W:  # a filler or a pad: times the zeroed last element of the LDS buffer, never x
+                        assert lc == zero_col and val[q] == 0
+                        n_fill += c >> 15
+                        xv = a.dtype.type(0)
+                    else:
+                        assert s * t.W + lc < x.size
+                        xv = x[s * t.W + lc]
+                    run = run + val[q] * xv
+                    if c >> 15:
+                        acc[row] = acc[row] + run
+                        row += 1
+                        run = a.dtype.type(0)
+                assert row == nrows, (g, u, si, row, nrows)
+            partial[g, rrow[u]:rrow[u + 1]] = acc
+    assert n_fill == t.n_dummies
     y = partial[0].copy()
-    for s in range(1, t.S):
-        y = y + partial[s]
-    geo = dict(W=t.W, S=t.S, B=t.B, WPB=t.WPB, n_packed=t.n_packed, n_dummies=t.n_dummies)
+    for g in range(1, t.NG):
+        y = y + partial[g]
+    geo = dict(W=t.W, S=t.S, NB=t.NB, NG=t.NG, GM=t.GM, WPB=t.WPB, n_packed=t.n_packed, n_dummies=t.n_dummies,
+               max_tile=t.max_tile, skewed=t.skewed)
     lib.spmv_striped_free.argtypes = [ctypes.POINTER(StripedHost)]
     lib.spmv_striped_free(ctypes.byref(t))
     return 0, (y, geo)
@@ -308,18 +336,40 @@ def test_striped_layout(lib, oracle, dtype):
     for rs, ci, a in cases:
         rows = rs.size - 1
         x = rng.standard_normal(int(ci.max())).astype(dtype)
-        rc, res = striped_emulate(lib, rs, ci, a, x)
-        assert rc == 0
-        y, geo = res
-        rc4, res4 = striped_emulate(lib, rs, ci, a, x, epl=8)
-        assert rc4 == 0 and np.array_equal(res4[0], y)  # same sums whatever the sub-window size
-        unit = 16 // a.dtype.itemsize
-        assert geo["S"] == -(-int(ci.max()) // geo["W"]) and (geo["W"] + unit) * a.dtype.itemsize <= 65536
-        assert geo["S"] * geo["B"] <= 6 and geo["W"] % unit == 0
-        assert geo["W"] - -(-int(ci.max()) // geo["S"]) < unit  # equal stripes, rounded up to 16 bytes of x
         y_ref = oracle.spmv(a, x, rs, ci, rows)
-        tol = (np.diff(rs) + geo["S"] + 2) * eps * oracle.absum(a, x, rs, ci, rows)
-        assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol)
+        absum = oracle.absum(a, x, rs, ci, rows)
+        seen = set()
+        for groups in (0, 1, 2, 1000):  # chosen; one group (a workgroup walks every stripe, no partials); two; one per stripe
+            rc, res = striped_emulate(lib, rs, ci, a, x, groups=groups)
+            assert rc == 0
+            y, geo = res
+            seen.add((geo["NG"], geo["NB"]))
+            unit = 16 // a.dtype.itemsize
+            assert geo["S"] == -(-int(ci.max()) // geo["W"]) and (geo["W"] + unit) * a.dtype.itemsize <= 65536
+            assert geo["W"] % unit == 0
+            assert geo["W"] - -(-int(ci.max()) // geo["S"]) < unit  # equal stripes, rounded up to 16 bytes of x
+            assert geo["NB"] * geo["WPB"] * 128 >= rows  # every wave range fits the accumulators
+            if groups == 0:
+                assert geo["NG"] * geo["NB"] <= max(6, -(-rows // (8 * 128)))
+            if groups == 1:
+                assert geo["NG"] == 1
+            tol = (np.diff(rs) + geo["S"] + 2) * eps * absum
+            assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol)
+        assert len(seen) >= 2 or geo["S"] == 1, seen
+
+
+def test_striped_wave_ranges_respect_the_accumulator_limit(lib):
+    """Rows of very unequal weight: the equal-weight cut must still keep every wave range within wave_rows rows
+    (the kernel's row accumulators are registers: lane l, register k <-> row 64 k + l) and leave no range empty."""
+    lens = np.concatenate([np.full(3000, 1), np.full(40, 900), np.full(2000, 2)]).astype(np.int64)
+    rs, ci, a = matgen.csr_from_lengths(np.random.default_rng(3), lens, 2000)
+    x = np.random.default_rng(4).standard_normal(2000)
+    rc, res = striped_emulate(lib, rs, ci, a, x, wgs=4, wave_rows=256)
+    assert rc == 0
+    y, geo = res
+    assert geo["NB"] * geo["WPB"] * 256 >= lens.size
+    ref = np.array([np.dot(a[rs[r] - 1:rs[r + 1] - 1], x[ci[rs[r] - 1:rs[r + 1] - 1] - 1]) for r in range(lens.size)])
+    assert np.allclose(y, ref, rtol=1e-12, atol=1e-12)
 
 
 def test_striped_rejects_hypersparse(lib):
@@ -336,14 +386,14 @@ from conftest import build_planlib
 from test_plan import StripedHost
 lib = ctypes.CDLL(build_planlib())
 rs, ci, a = matgen.random_csr(77, 9000, 40000, 60)
-t = StripedHost()
-lib.spmv_striped_build.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 8 + [ctypes.POINTER(StripedHost)]
-assert lib.spmv_striped_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, 9000, 40000, 8, 65536, 8, 24, 4, ctypes.byref(t)) == 0
+from test_plan import striped_build
+rc, t = striped_build(lib, rs, ci, a, 65536, 8, 24, 128, 0)
+assert rc == 0
 h = hashlib.sha256()
 h.update(np.ctypeslib.as_array(t.col, (t.n_packed,)).tobytes())
 h.update(np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctypes.c_double)), (t.n_packed,)).tobytes())
-h.update(np.ctypeslib.as_array(t.wptr, (t.n_waves + 1,)).tobytes())
-h.update(np.ctypeslib.as_array(t.wrow, (t.n_waves + 1,)).tobytes())
+h.update(np.ctypeslib.as_array(t.tptr, (t.NG * t.n_ranges * (t.GM + 1),)).tobytes())
+h.update(np.ctypeslib.as_array(t.rrow, (t.n_ranges + 1,)).tobytes())
 print(h.hexdigest(), t.n_packed, t.n_dummies)
 """
 
@@ -362,144 +412,3 @@ def test_striped_layout_does_not_depend_on_the_thread_count():
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.strip())
     assert outs[0] == outs[1] == outs[2] and len(outs[0].split()[0]) == 64
-
-
-# ------------------------------------------------------------------ LANES layout (csrc/spmv_lanes.c)
-class LanesHost(ctypes.Structure):
-    _fields_ = [("elem", ctypes.c_int), ("W", ctypes.c_int), ("S", ctypes.c_int), ("WPB", ctypes.c_int),
-                ("B", ctypes.c_int), ("n_waves", ctypes.c_int), ("n_packed", ctypes.c_int64),
-                ("n_pad", ctypes.c_int64), ("n_slots", ctypes.c_int64), ("val", ctypes.c_void_p),
-                ("col", ctypes.POINTER(ctypes.c_uint16)), ("wptr", ctypes.POINTER(ctypes.c_int32)),
-                ("wslot", ctypes.POINTER(ctypes.c_int32)), ("islot", ctypes.POINTER(ctypes.c_int32))]
-
-
-def lanes_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6):
-    """Runs csrc/spmv_lanes.c, checks the invariants k_lanes relies on and walks the layout exactly like
-    the kernel: every lane on its own, slot numbers from the boustrophedon sequence, no row numbers."""
-    rows = rs.size - 1
-    cols = int(ci.max()) if ci.size else 0
-    t = LanesHost()
-    lib.spmv_lanes_build.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 7 + [ctypes.POINTER(LanesHost)]
-    rc = lib.spmv_lanes_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, rows, cols, a.dtype.itemsize,
-                              xbytes, wpb, wgs, ctypes.byref(t))
-    if rc != 0:
-        return rc, None
-    nw = t.n_waves
-    assert nw == t.S * t.B * t.WPB
-    wptr = np.ctypeslib.as_array(t.wptr, (nw + 1,)).astype(np.int64)
-    wslot = np.ctypeslib.as_array(t.wslot, (nw + 1,)).astype(np.int64)
-    islot = np.ctypeslib.as_array(t.islot, (t.S * rows,)).astype(np.int64).reshape(t.S, rows)
-    col = np.ctypeslib.as_array(t.col, (t.n_packed + 1,)).astype(np.int64)[:t.n_packed]
-    ctype = ctypes.c_double if a.dtype == np.float64 else ctypes.c_float
-    val = np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctype)), (t.n_packed + 1,))[:t.n_packed]
-    assert np.all(wptr % 256 == 0) and np.all(np.diff(wptr) >= 0) and wptr[-1] == t.n_packed
-    assert wslot[-1] == t.n_slots and np.all(np.diff(wslot) >= 0)
-    G = 16 // a.dtype.itemsize
-    # every non-empty (stripe, row) pair owns exactly one slot, and one flagged entry exists per slot
-    rowid = np.repeat(np.arange(rows), np.diff(rs))
-    cnt = np.zeros((t.S, rows), np.int64)
-    np.add.at(cnt, ((ci.astype(np.int64) - 1) // t.W, rowid), 1)
-    assert np.array_equal(islot >= 0, cnt > 0)
-    used = np.sort(islot[islot >= 0])
-    assert used.size == np.unique(used).size and (used.size == 0 or used[-1] < t.n_slots)
-    assert int((col >> 15).sum()) == used.size
-    assert t.n_pad == t.n_packed - ci.size
-    partial = np.full(t.n_slots + 1, np.nan, a.dtype)
-    per = t.B * t.WPB
-    xs = np.zeros(t.S * t.W + 1, a.dtype)
-    xs[:x.size] = x
-    QUEUE = 4
-    n_direct = 0
-    for wi in range(nw):
-        s = wi // per
-        p0, p1 = int(wptr[wi]), int(wptr[wi + 1])
-        nq = (p1 - p0) // 256
-        s0, s1 = int(wslot[wi]), int(wslot[wi + 1])
-        assert (s1 - s0) % 64 == 0
-        if nq == 0:
-            assert s0 == s1
-            continue
-        ngroups = (s1 - s0) // 64
-        c = col[p0:p1].reshape(nq, 64, 4)  # [sub-window][lane][entry of the lane]
-        v = val[p0:p1].reshape(nq, 4 // G, 64, G).transpose(0, 2, 1, 3).reshape(nq, 64, 4)  # undo the 16-byte interleave
-        # the kernel in lockstep: per-lane queue of QUEUE finished sums, groups leave in order as soon as every
-        # lane is past them; a lane QUEUE or more groups ahead stores directly and masks its slot of that group
-        acc = np.zeros(64, a.dtype)
-        kseg = np.zeros(64, np.int64)
-        queue = np.full((QUEUE, 64), np.nan, a.dtype)
-        direct = np.zeros((32, 64), bool)
-        gflushed = 0
-        written = np.zeros(s1 - s0, np.int64)
-
-        def write_out(g, only=None):
-            sel = ~direct[g % 32] if only is None else (only & ~direct[g % 32])
-            idx = s0 + 64 * g + np.nonzero(sel)[0]
-            partial[idx] = queue[g % QUEUE][sel]
-            written[idx - s0] += 1
-            direct[g % 32] = False
-
-        for q in range(nq):
-            for i in range(4):
-                cc = c[q, :, i]
-                acc = acc + v[q, :, i] * xs[s * t.W + (cc & 0x7fff)]
-                for lane in np.nonzero((cc >> 15) != 0)[0]:
-                    k = int(kseg[lane])
-                    assert k < ngroups and k - gflushed < 32
-                    if k - gflushed < QUEUE:
-                        queue[k % QUEUE, lane] = acc[lane]
-                    else:
-                        partial[s0 + 64 * k + lane] = acc[lane]
-                        written[64 * k + lane] += 1
-                        assert not direct[k % 32, lane]
-                        direct[k % 32, lane] = True
-                        n_direct += 1
-                    kseg[lane] += 1
-                    acc[lane] = 0
-            while gflushed + 1 < ngroups and np.all(kseg > gflushed):  # once per sub-window
-                write_out(gflushed)
-                gflushed += 1
-        while gflushed < ngroups:
-            write_out(gflushed, only=kseg > gflushed)
-            gflushed += 1
-        assert not direct.any() and written.max() <= 1
-        assert written.sum() == int(kseg.sum())  # every finished segment reached memory exactly once
-    assert not np.isnan(partial[islot[islot >= 0]]).any()
-    y = np.zeros(rows, a.dtype)
-    for s in range(t.S):
-        y = y + np.where(islot[s] >= 0, partial[np.maximum(islot[s], 0)], a.dtype.type(0))
-    geo = dict(W=t.W, S=t.S, B=t.B, WPB=t.WPB, n_packed=t.n_packed, n_pad=t.n_pad, n_slots=t.n_slots, n_direct=n_direct)
-    lib.spmv_lanes_free.argtypes = [ctypes.POINTER(LanesHost)]
-    lib.spmv_lanes_free(ctypes.byref(t))
-    return 0, (y, geo)
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_lanes_layout(lib, oracle, dtype):
-    rng = np.random.default_rng(6)
-    eps = 2.0 ** -53 if dtype == np.float64 else 2.0 ** -24
-    cases = [matgen.random_csr(18, 900, 30000, 40, dtype, empty_frac=0.05, sort_cols=False, distinct=False),
-             matgen.npb_like(19, 700, 120, dtype),
-             matgen.random_csr(20, 50, 20000, 300, dtype),
-             matgen.random_csr(21, 3000, 9000, 6, dtype, empty_frac=0.3),  # many empty (row, stripe) pairs: no fillers
-             matgen.csr_from_lengths(rng, [30] + [1] * 5000 + [25] + [2] * 700, 8000, dtype)]  # one lane held up while the others run through 1-entry segments
-    hit_direct = False
-    for rs, ci, a in cases:
-        rows = rs.size - 1
-        x = rng.standard_normal(int(ci.max())).astype(dtype)
-        rc, res = lanes_emulate(lib, rs, ci, a, x, wgs=1 if rs.size > 5000 else 6)  # few, long waves for the last case
-        assert rc == 0
-        y, geo = res
-        assert geo["S"] == -(-int(ci.max()) // geo["W"]) and geo["S"] * geo["B"] <= 6
-        hit_direct = hit_direct or geo["n_direct"] > 0
-        y_ref = oracle.spmv(a, x, rs, ci, rows)
-        tol = (np.diff(rs) + geo["S"] + 2) * eps * oracle.absum(a, x, rs, ci, rows)
-        assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol)
-    assert hit_direct  # the overflow path of the queue was exercised
-
-
-def test_lanes_rejects_one_huge_row(lib):
-    """A row that is most of the matrix would leave 63 lanes of its wave padding: not worth it."""
-    rng = np.random.default_rng(7)
-    rs, ci, a = matgen.csr_from_lengths(rng, [29000] * 8 + [3] * 30000, 30000, np.float64)
-    rc, _ = lanes_emulate(lib, rs, ci, a, np.ones(30000), wgs=1)
-    assert rc == -2

@@ -20,7 +20,7 @@ import pkgload  # noqa: E402
 
 
 def build_case(pkg, name, dtype):
-    if name in ("S", "W", "A", "B", "C"):
+    if name in ("S", "W", "A", "B", "C", "D"):
         m = pkg.npb.NpbMatrix(name)
         a = m.a if dtype == np.float64 else m.a.astype(np.float32)
         return m.rowstr, m.colidx, a, m  # keep m alive
@@ -55,10 +55,12 @@ def main():
     ap.add_argument("--xbytes", type=int, default=32768, help="bytes of x per LDS stripe of the TILED kernel")
     ap.add_argument("--blocks", type=int, default=0, help="TILED workgroups aimed for (0 = default 512)")
     ap.add_argument("--tk", type=int, default=0, help="TILED: 256-entry sub-windows per register window")
-    ap.add_argument("--sx", type=int, default=131072, help="STRIPED: bytes of x per stripe (65536|131072)")
-    ap.add_argument("--swpb", type=int, default=16, help="STRIPED: waves per workgroup (8|16)")
-    ap.add_argument("--sepl", type=int, default=4, help="STRIPED: entries per lane per sub-window (4|8)")
     ap.add_argument("--swgs", type=int, default=256, help="STRIPED: workgroups aimed for")
+    ap.add_argument("--sgroups", default="0", help="STRIPED: comma list of stripe-group counts to time (0 = the builder's choice); "
+                                                   "each value builds the layout anew")
+    ap.add_argument("--swrows", type=int, default=1024, help="STRIPED: most rows per wave range (multiple of 64, <= 1024)")
+    ap.add_argument("--abl", default="0", help="STRIPED: comma list of ablation bit masks to time after the real kernel (1 no fold, "
+                                              "2 plain partial stores, 4 no accumulator updates, 8 no ring writes); results are wrong")
     ap.add_argument("--plans", default="", help="comma list of plan names to run (default all)")
     args = ap.parse_args()
     pkg = pkgload.load_package()
@@ -68,11 +70,11 @@ def main():
     be.set_tuning(3, args.xbytes)
     be.set_tuning(4, args.blocks)
     be.set_tuning(5, args.tk)
-    be.set_tuning(7, args.sx)
-    be.set_tuning(8, args.swpb)
     be.set_tuning(9, args.swgs)
-    be.set_tuning(10, args.sepl)
-    plans = [("lanes", pkg.PLAN_LANES, 0), ("striped", pkg.PLAN_STRIPED, 0), ("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
+    be.set_tuning(12, args.swrows)
+    groups = [int(v) for v in args.sgroups.split(",")]
+    be.set_tuning(11, groups[0])
+    plans = [("striped", pkg.PLAN_STRIPED, 0), ("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
              ("vec16", pkg.PLAN_VECTOR, 16), ("vec8", pkg.PLAN_VECTOR, 8), ("vec4", pkg.PLAN_VECTOR, 4),
              ("vec1", pkg.PLAN_VECTOR, 1), ("binned", pkg.PLAN_BINNED, 0), ("ordered", pkg.PLAN_ORDERED, 0),
              ("auto", pkg.PLAN_AUTO, 0)]
@@ -113,9 +115,31 @@ def main():
                     print("%-10s %-4s %-8s %-9s %10.2f %10.1f %8.1f   launches=%d" % (
                         case, dts, pname, tun, ms * 1e3, i2["algorithmic_bytes"] / ms / 1e6,
                         2.0 * i2["nnz"] / ms / 1e6, i2["n_launches"]), flush=True)
+                    if pname == "striped":
+                        for ab in [int(v) for v in args.abl.split(",") if int(v)]:
+                            be.set_tuning(6, ab)
+                            dm.time_device(dx, dy, 3)
+                            ms = dm.time_device(dx, dy, reps) / reps
+                            be.set_tuning(6, 0)
+                            print("%-10s %-4s %-8s %-9s %10.2f   (ablation %d: timing only)" % (case, dts, pname, tun, ms * 1e3, ab), flush=True)
             be.set_tuning(0, 1)
             be.set_tuning(1, 0)
             dm.close()
+            for ng in groups[1:]:  # the STRIPED layout again with other stripe groups (a layout is built once per matrix object)
+                be.set_tuning(11, ng)
+                dm = be.matrix(a, rs, ci, rows, cols_hint=(keep.na if case.startswith("D/") else 0))
+                try:
+                    dm.set_plan(pkg.PLAN_STRIPED, 0)
+                    dm.time_device(dx, dy, 3)
+                    ms = dm.time_device(dx, dy, args.reps) / args.reps
+                    i2 = dm.info()
+                    print("%-10s %-4s %-8s %-9s %10.2f %10.1f %8.1f   workgroups=%d" % (
+                        case, dts, "striped", "groups=%d" % ng, ms * 1e3, i2["algorithmic_bytes"] / ms / 1e6,
+                        2.0 * i2["nnz"] / ms / 1e6, i2["n_blocks"]), flush=True)
+                except RuntimeError as e:
+                    print("%-10s %-4s %-8s groups=%d unavailable: %s" % (case, dts, "striped", ng, e), flush=True)
+                dm.close()
+            be.set_tuning(11, groups[0])
             be.free(dx)
             be.free(dy)
             del keep

@@ -20,7 +20,7 @@ import json
 import sys
 from collections import defaultdict
 
-FETCH_CORRECTION = {"k_striped": 2.12, "k_lanes": 2.12, "k_tiled": 2.12, "default": 2.0}
+FETCH_CORRECTION = {"k_striped": 2.12, "k_tiled": 2.12, "default": 2.0}
 
 
 def per_kernel(path, counter):
@@ -33,7 +33,7 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    for k in ("k_striped", "k_stripe_sum", "k_lanes", "k_lane_sum", "k_tiled", "k_stream", "k_long"):
+    for k in ("k_striped", "k_tiled", "k_stream", "k_long"):
         if k in name:
             return k
     return None
@@ -43,7 +43,7 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"kernels": {}, "hbm_bytes_per_spmv": 0.0,
-           "correction": "FETCH_SIZE x2.12 for the 16-byte + 8-byte load mix of k_striped / k_lanes / k_tiled, x2.00 "
+           "correction": "FETCH_SIZE x2.12 for the 16-byte + 8-byte load mix of k_striped / k_tiled, x2.00 "
                          "otherwise (gfx950 counts half of wide reads; calibrated in round 1); WRITE_SIZE exact"}
     total = 0.0
     for name, (fb, n) in sorted(fetch.items()):

@@ -3,7 +3,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import pkgload
 pkg = pkgload.load_package()
 be = pkg.Backend()
-for cls, plans in (("C", [pkg.PLAN_AUTO, pkg.PLAN_LANES, pkg.PLAN_TILED, pkg.PLAN_STREAM]), ("B", [pkg.PLAN_AUTO])):
+for cls, plans in (("C", [pkg.PLAN_AUTO, pkg.PLAN_TILED, pkg.PLAN_STREAM]), ("B", [pkg.PLAN_AUTO])):
     m = pkg.npb.NpbMatrix(cls)
     dm = be.matrix(m.a, m.rowstr, m.colidx, m.rows)
     x = np.random.default_rng(3).standard_normal(m.na + 2)
