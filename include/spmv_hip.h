@@ -103,6 +103,19 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
 int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int reps, void *stream,
                          float *ms_total);
 
+/*
+ * The traffic of one ABI call around the kernel (libspmv/gpu.c:264,285), `reps` times on one stream between two
+ * HIP events: x_host -> x_dev (cols elements), y = A x, y_dev -> y_host (the matrix's rows).  For the row-
+ * partitioned path y_host is the address of this block's slice of the caller's y (the host gather).
+ */
+int spmv_hip_time_call(spmv_hip_matrix *m, const void *x_host, void *y_host, void *x_dev, void *y_dev, int reps,
+                       void *stream, float *ms_total);
+/* pinned host memory for the above (and for callers that want DMA transfers): allocate, or pin in place */
+void *spmv_hip_host_alloc(size_t bytes);
+void spmv_hip_host_free(void *p);
+int spmv_hip_host_register(void *p, size_t bytes);
+void spmv_hip_host_unregister(void *p);
+
 /* ---- opt-in device-resident CG step (csrc/spmv_cg.hip) ---------- */
 /*
  * NPB's conj_grad (NPB3.3.1/CG/cg.f:447-644) with p, q, r, z, x kept on the GPU: 25 x {SpMV,

@@ -71,6 +71,14 @@ class Backend:
         L.spmv_hip_spmv_device.argtypes = [ctypes.c_void_p] * 4
         L.spmv_hip_time_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.spmv_hip_time_call.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.spmv_hip_host_alloc.restype = ctypes.c_void_p
+        L.spmv_hip_host_alloc.argtypes = [ctypes.c_size_t]
+        L.spmv_hip_host_free.argtypes = [ctypes.c_void_p]
+        L.spmv_hip_host_free.restype = None
+        L.spmv_hip_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.spmv_hip_host_unregister.argtypes = [ctypes.c_void_p]
+        L.spmv_hip_host_unregister.restype = None
         L.spmv_hip_partition_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.spmv_hip_partition_rows.restype = None
         L.spmv_hip_malloc.restype = ctypes.c_void_p
@@ -180,6 +188,14 @@ class Backend:
         if self.lib.spmv_hip_synchronize(device) != 0:
             raise RuntimeError(self.last_error())
 
+    def host_register(self, arr):
+        """Pins a host array in place (hipHostRegister) so that copies from / to it are DMA transfers; False when the
+        runtime declines (the array then still works as pageable memory)."""
+        return self.lib.spmv_hip_host_register(_ptr(arr), arr.nbytes) == 0
+
+    def host_unregister(self, arr):
+        self.lib.spmv_hip_host_unregister(_ptr(arr))
+
     def matrix(self, a, rowstr, colidx, rows, device=0, row_begin=0, row_end=None, cols_hint=0):
         return Matrix(self, a, rowstr, colidx, rows, device, row_begin, row_end, cols_hint)
 
@@ -216,6 +232,14 @@ class Matrix:
     def time_device(self, x_dev, y_dev, reps, stream=None):
         ms = ctypes.c_float(0)
         if self.be.lib.spmv_hip_time_device(self.h, x_dev, y_dev, reps, stream, ctypes.byref(ms)) != 0:
+            raise RuntimeError(self.be.last_error())
+        return float(ms.value)
+
+    def time_call(self, x_host, y_host_slice, x_dev, y_dev, reps, stream=None):
+        """reps x {x_host -> x_dev, y = A x, y_dev -> y_host_slice} on one stream between two HIP events (ms)."""
+        ms = ctypes.c_float(0)
+        if self.be.lib.spmv_hip_time_call(self.h, _ptr(x_host), _ptr(y_host_slice), x_dev, y_dev, reps, stream,
+                                          ctypes.byref(ms)) != 0:
             raise RuntimeError(self.be.last_error())
         return float(ms.value)
 

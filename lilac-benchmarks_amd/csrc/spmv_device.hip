@@ -951,6 +951,45 @@ int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int
     return rc;
 }
 
+/*
+ * What one ABI call moves besides the kernel (libspmv/gpu.c:264,285): x from host memory to the device, the
+ * product, y back to host memory -- `reps` times back to back on one stream, bracketed by HIP events.  The
+ * host pointers should be pinned (spmv_hip_host_alloc / spmv_hip_host_register) for the copies to be DMA
+ * transfers that overlap nothing but themselves; pageable memory works and is slower.  y_host receives the
+ * matrix's rows, i.e. a rank of the row-partitioned path passes the address of ITS slice of the shared y.
+ */
+int spmv_hip_time_call(spmv_hip_matrix *m, const void *x_host, void *y_host, void *x_dev, void *y_dev, int reps,
+                       void *stream, float *ms_total)
+{
+    if (!m || reps <= 0 || !ms_total || !x_host || !y_host)
+        return -1;
+    HIPCHK(hipSetDevice(m->device), return -1);
+    hipStream_t st = stream_of(m->device, stream);
+    DevCtx &dc = g_dev[m->device];
+    if (!dc.ev[0]) {
+        HIPCHK(hipEventCreate(&dc.ev[0]), return -1);
+        HIPCHK(hipEventCreate(&dc.ev[1]), return -1);
+    }
+    const size_t xb = (size_t)m->cols * m->elem, yb = (size_t)m->rows * m->elem;
+    HIPCHK(hipEventRecord(dc.ev[0], st), return -1);
+    for (int i = 0; i < reps; ++i) {
+        HIPCHK(hipMemcpyAsync(x_dev, x_host, xb, hipMemcpyHostToDevice, st), return -1);
+        if (spmv_hip_spmv_device(m, x_dev, y_dev, st))
+            return -1;
+        if (yb)
+            HIPCHK(hipMemcpyAsync(y_host, y_dev, yb, hipMemcpyDeviceToHost, st), return -1);
+    }
+    HIPCHK(hipEventRecord(dc.ev[1], st), return -1);
+    HIPCHK(hipEventSynchronize(dc.ev[1]), return -1);
+    HIPCHK(hipEventElapsedTime(ms_total, dc.ev[0], dc.ev[1]), return -1);
+    return 0;
+}
+
+void *spmv_hip_host_alloc(size_t bytes) { return spmvd_host_alloc(bytes); }
+void spmv_hip_host_free(void *p) { spmvd_host_free(p); }
+int spmv_hip_host_register(void *p, size_t bytes) { return spmvd_host_register(p, bytes); }
+void spmv_hip_host_unregister(void *p) { spmvd_host_unregister(p); }
+
 void spmv_hip_set_tuning(int key, int value)
 {
     if (key == 2)

@@ -544,6 +544,57 @@ static slot *slot_victim(void)
     return best;
 }
 
+typedef struct colmax_ctx {
+    const int *c;
+    int max;
+} colmax_ctx;
+
+static void colmax_range(int64_t lo, int64_t hi, void *v)
+{
+    colmax_ctx *cc = (colmax_ctx *)v;
+    int mx = 0;
+    for (int64_t j = lo; j < hi; ++j)
+        mx = cc->c[j] > mx ? cc->c[j] : mx;
+    int seen = __atomic_load_n(&cc->max, __ATOMIC_RELAXED);
+    while (mx > seen && !__atomic_compare_exchange_n(&cc->max, &seen, mx, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
+        ;
+}
+
+typedef struct upload_job {
+    slot *sl;
+    int p;
+    const void *a;
+    const int *rowstr, *colidx;
+    int rows, elem, cols_hint, ok;
+    char err[400];
+    pthread_t th;
+} upload_job;
+
+/* uploads part p of the slot: device CSR block + plan, x and y buffers; errors are reported by the caller */
+static void *upload_part(void *v)
+{
+    upload_job *j = (upload_job *)v;
+    slot *sl = j->sl;
+    const int p = j->p, dev = sl->part_dev[p];
+    sl->part[p] = spmv_hip_matrix_create(j->a, j->rowstr, j->colidx, j->rows, j->elem, dev, sl->bounds[p],
+                                         sl->bounds[p + 1], sl->nparts == 1 ? 0 : j->cols_hint);
+    int ok = sl->part[p] != NULL;
+    if (ok && G.plan != SPMV_HIP_PLAN_AUTO)
+        ok = spmv_hip_matrix_set_plan(sl->part[p], G.plan, G.plan_param) == 0;
+    if (ok) {
+        spmv_hip_info inf;
+        spmv_hip_matrix_info(sl->part[p], &inf);
+        const size_t prow = (size_t)(sl->bounds[p + 1] - sl->bounds[p]);
+        sl->dx[p] = spmv_hip_malloc(dev, ((size_t)inf.cols + 1) * j->elem);
+        sl->dy[p] = spmv_hip_malloc(dev, (prow + 1) * j->elem);
+        ok = sl->dx[p] && sl->dy[p];
+    }
+    if (!ok)
+        snprintf(j->err, sizeof j->err, "%s", spmv_hip_last_error()); /* the message is per thread */
+    j->ok = ok;
+    return NULL;
+}
+
 static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *colidx, int rows,
                         int64_t nnz, int elem)
 {
@@ -562,30 +613,47 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
 
     const int churning = G.cache == CACHE_OFF || churn_note(a, rowstr, colidx, 0) >= 2;
     spmvd_set_relayout(!churning);
+    /* the length of x: max(colidx) over the WHOLE matrix (libspmv/gpu.c:217-223); one part finds it on the device
+     * while it uploads, several parts need it up front so that they can upload side by side */
     int cols = 0;
-    for (int p = 0; p < sl->nparts; ++p) {
-        int dev = p % G.ndev;
-        sl->part_dev[p] = dev;
-        sl->part[p] = spmv_hip_matrix_create(a, rowstr, colidx, rows, elem, dev, sl->bounds[p],
-                                             sl->bounds[p + 1], sl->nparts == 1 ? 0 : cols);
-        if (!sl->part[p])
-            die("matrix upload failed: %s", spmv_hip_last_error());
-        if (G.plan != SPMV_HIP_PLAN_AUTO)
-            CHECK(spmv_hip_matrix_set_plan(sl->part[p], G.plan, G.plan_param));
-        spmv_hip_info inf;
-        spmv_hip_matrix_info(sl->part[p], &inf);
-        cols = inf.cols; /* part 0 scans the whole colidx; later parts reuse it */
+    if (sl->nparts > 1) {
+        colmax_ctx cc = {colidx + (rowstr[0] - 1), 0};
+        spmv_parallel_for(nnz, 1 << 20, colmax_range, &cc);
+        cols = cc.max;
     }
+    upload_job job[MAX_PARTS];
+    for (int p = 0; p < sl->nparts; ++p) {
+        sl->part_dev[p] = p % G.ndev;
+        memset(&job[p], 0, sizeof job[p]);
+        job[p].sl = sl, job[p].p = p, job[p].a = a, job[p].rowstr = rowstr, job[p].colidx = colidx;
+        job[p].rows = rows, job[p].elem = elem, job[p].cols_hint = cols;
+    }
+    /*
+     * One host thread per part: each uploads its row block to its device, re-lays it out and allocates its x / y
+     * (class D over 8 parts: the conversions ran one after the other for about 4 s; side by side they take as long
+     * as the slowest).  Part 0 runs on the calling thread.
+     */
+    int started = 0;
+    for (int p = 1; p < sl->nparts; ++p) {
+        if (pthread_create(&job[p].th, NULL, upload_part, &job[p]) != 0)
+            break;
+        started = p;
+    }
+    upload_part(&job[0]);
+    for (int p = 1; p <= started; ++p)
+        pthread_join(job[p].th, NULL);
+    for (int p = started + 1; p < sl->nparts; ++p) /* threads that could not be started */
+        upload_part(&job[p]);
     spmvd_set_relayout(1);
-    sl->cols = cols;
-    for (int p = 0; p < sl->nparts; ++p) {
-        int dev = sl->part_dev[p];
-        size_t prow = (size_t)(sl->bounds[p + 1] - sl->bounds[p]);
-        sl->dx[p] = spmv_hip_malloc(dev, ((size_t)cols + 1) * elem);
-        sl->dy[p] = spmv_hip_malloc(dev, (prow + 1) * elem);
-        if (!sl->dx[p] || !sl->dy[p])
-            die("vector allocation failed: %s", spmv_hip_last_error());
+    for (int p = 0; p < sl->nparts; ++p)
+        if (!job[p].ok)
+            die("matrix upload failed (part %d of %d): %s", p, sl->nparts, job[p].err);
+    if (sl->nparts == 1) {
+        spmv_hip_info inf;
+        spmv_hip_matrix_info(sl->part[0], &inf);
+        cols = inf.cols;
     }
+    sl->cols = cols;
 
     /* arm write detection AFTER the upload (the copies read the arrays) */
     if (G.cache != CACHE_OFF) {

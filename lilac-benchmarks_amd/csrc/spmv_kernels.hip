@@ -718,12 +718,14 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const unsi
         /* inclusive segmented scan of (tailv, has) over the wave */
         T sv = tailv;
         int sf = has;
+        if (!(abl & 16)) {
         segscan_step<T, 0x111, 0xf>(sv, sf); /* row_shr:1 */
         segscan_step<T, 0x112, 0xf>(sv, sf); /* row_shr:2 */
         segscan_step<T, 0x114, 0xf>(sv, sf); /* row_shr:4 */
         segscan_step<T, 0x118, 0xf>(sv, sf); /* row_shr:8 */
         segscan_step<T, 0x142, 0xa>(sv, sf); /* row_bcast:15 */
         segscan_step<T, 0x143, 0xc>(sv, sf); /* row_bcast:31 */
+        }
         if (!sf)
             sv = sv + carry; /* no row end at or before this lane: the previous sub-window's open sum */
         T cin = dpp_mov<0x138, 0xf>(sv); /* wave_shr:1: what the lane below leaves open */

@@ -13,7 +13,7 @@
 
 #include "spmv_internal.h"
 
-static char g_err[256];
+static _Thread_local char g_err[256]; /* per thread, like the real layer: parts upload side by side */
 void spmv_set_error(const char *fmt, ...)
 {
     va_list ap;
@@ -73,8 +73,8 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     m->cols = cols_hint > 0 ? cols_hint : mx;
     m->relayout = g_relayout;
     m->plan = g_relayout && m->rows >= 1000 ? SPMV_HIP_PLAN_STRIPED : SPMV_HIP_PLAN_STREAM;
-    mock_creates++;
-    mock_relayout_creates += m->plan == SPMV_HIP_PLAN_STRIPED;
+    __atomic_fetch_add(&mock_creates, 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&mock_relayout_creates, m->plan == SPMV_HIP_PLAN_STRIPED, __ATOMIC_RELAXED);
     return m;
 }
 void spmv_hip_matrix_destroy(spmv_hip_matrix *m)

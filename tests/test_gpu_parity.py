@@ -450,6 +450,53 @@ def test_abi_policies_in_a_fresh_process(env, uploads, exact):
     assert int(out[4]) == 3000
 
 
+CLASS_D_SCRIPT = """
+import sys, time
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, pkgload
+from oracle.oracle import Oracle
+p = pkgload.load_package(); be = p.Backend(); o = Oracle()
+t0 = time.time(); m = p.npb.NpbMatrix("D"); t_gen = time.time() - t0
+rows = m.na
+x = np.random.default_rng(404).standard_normal(rows + 2); y = np.full(rows, np.nan)
+t0 = time.time(); be.harness(y, m.a, x, m.rowstr, m.colidx, rows); t_first = time.time() - t0
+ref = o.spmv(m.a, x, m.rowstr, m.colidx, rows); ab = o.absum(m.a, x, m.rowstr, m.colidx, rows)
+bad = int(np.count_nonzero(~(np.abs(y - ref) <= (np.diff(m.rowstr) + 24.0) * 2.0**-53 * ab)))
+y2 = np.full(rows, np.nan); be.harness(y2, m.a, x, m.rowstr, m.colidx, rows)
+same = bool(np.array_equal(y.view(np.uint64), y2.view(np.uint64)))
+s0 = be.stats(); inf = be.abi_matrix_info()
+be.reset_stats()
+res = m.run_cg(be.harness_fn())
+s = be.stats()
+print("CLASSD", bad, int(same), s0["uploads"], "%%.3f" %% s0["t_upload"], inf["rows"], inf["nnz"], inf["plan"],
+      res["verified"], "%%.13f" %% res["zeta"], "%%.3e" %% res["err"], res["spmv_calls"], s["uploads"],
+      "%%.2f" %% res["t_bench"], "%%.1f" %% res["mops"], "%%.1f" %% t_gen, "%%.2f" %% t_first)
+"""
+
+
+@pytest.mark.parametrize("parts", ["1", "8"])
+def test_class_d_through_the_abi(parts):
+    """BASELINE configs[4]: NPB class D (1.5 M rows, 694 392 620 nonzeros) through spmv_harness_ in a fresh process --
+    whole on the one GPU, and cut into 8 row partitions of equal nonzero count (SPMV_HIP_PARTS=8 wraps the parts onto
+    the GPUs there are: x to every part's device copy, 8 kernels on their streams, each y slice copied straight to
+    its row offset of the caller's vector: the multi-GPU code path of the library).  One product is compared row by
+    row with one oracle pass, a repetition must give the same bits, then the complete benchmark -- 2626 calls --
+    must meet cg.f:363-368 against zeta = 52.514532105794 (cg.f:122-163)."""
+    code = CLASS_D_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__))
+    env = dict(os.environ, SPMV_HIP_PARTS=parts)
+    proc = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          env=env, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    out = [l for l in proc.stdout.splitlines() if l.startswith("CLASSD")][0].split()
+    print(" ".join(out))
+    bad, same, uploads, t_upload, rows, nnz, plan, verified, zeta, err, calls, uploads_cg = out[1:13]
+    assert int(bad) == 0 and int(same) == 1
+    assert int(uploads) == 1 and int(uploads_cg) == 0  # uploaded once, cached for the 2626 calls of the benchmark
+    assert int(rows) == 1500000 and int(nnz) == 694392620  # SURVEY 8(a) a3, measured on the reference's structure
+    assert int(verified) == 1 and float(err) <= 1e-10 and abs(float(zeta) - 52.514532105794) <= 1e-10 * 52.514532105794
+    assert int(calls) == 2626
+
+
 # ------------------------------------------------------------------ BASELINE's full size, by properties
 def test_class_c_full_size(pkg, backend, oracle):
     """NPB class C (150000 rows, 36121058 nonzeros): the bench workload itself."""

@@ -36,7 +36,7 @@ HARNESS_SOURCES = [os.path.join(ROOT, "tests", "native", f) for f in ("harness_d
     os.path.join(CSRC, f) for f in ("spmv_harness.c", "spmv_plan.c")]
 
 
-@pytest.mark.parametrize("san", ["", "address,undefined"])
+@pytest.mark.parametrize("san", ["", "address,undefined", "thread"])
 def test_abi_harness_on_a_mock_device(tmp_path, san):
     """spmv_harness.c -- cache slots, page-protection and byte-compare write detection, the cache policies,
     churn, the zero-copy path, float next to double, degenerate shapes -- linked against a mock device layer
@@ -53,10 +53,14 @@ def test_abi_harness_on_a_mock_device(tmp_path, san):
         pytest.skip("this gcc has no %s runtime" % san)
     assert cc.returncode == 0, cc.stdout[-3000:]
     runs = [({"SPMV_HIP_CACHE": p}, p) for p in ("mprotect", "compare", "pointer", "off")]
+    if san == "thread":  # the parts of a row partition upload on one host thread each (slot_upload)
+        runs = [({"SPMV_HIP_PARTS": "3", "SPMV_HIP_CACHE": "compare", "SPMV_HIP_ZEROCOPY": "0"}, "compare")]
     runs += [({"SPMV_HIP_PARTS": "3", "SPMV_HIP_ZEROCOPY": "0"}, "mprotect"), ({"SPMV_HIP_PIN": "register"}, "mprotect"),
              ({"SPMV_HIP_PIN": "pageable"}, "mprotect"), ({"MOCK_NO_DEVPTR": "1"}, "mprotect")]
     for env, policy in runs:
-        e = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1", **env)
+        e = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1", TSAN_OPTIONS="halt_on_error=1",
+                 **env)
         r = subprocess.run([exe, policy], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=e, timeout=300)
         assert r.returncode == 0 and "all scenarios passed" in r.stdout, (env, r.stdout[-3000:])
         assert "runtime error" not in r.stdout and "ERROR: AddressSanitizer" not in r.stdout, (env, r.stdout[-3000:])
+        assert "WARNING: ThreadSanitizer" not in r.stdout, (env, r.stdout[-3000:])
