@@ -370,7 +370,14 @@ def main():
             "steps": ksteps, "nnz": int(md.nnz), "plan": pkg.abi.PLAN_NAMES[infd["plan"]],
             "roofline_frac": round(infd["algorithmic_bytes"] / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": infd["algorithmic_bytes"], "generated_s": round(t_gen, 1),
+            "launches_per_step": infd["n_launches"], "workgroups": infd["n_blocks"],
         }
+        try:  # stored PMC figure of this workload (profiles/traffic.json), not measured by this run
+            ent = json.load(open(tpath)).get("D/%s" % pkg.abi.PLAN_NAMES[infd["plan"]], {})
+            line["scale_ref"]["traffic"] = ent.get("hbm_bytes_per_launch")
+            line["scale_ref"]["traffic_source"] = ent.get("source")
+        except Exception:
+            pass
         dmd.close()
         be.free(dxd, device)
         be.free(dyd, device)

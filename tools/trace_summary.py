@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """tools/trace_summary.py -- per (kernel, grid size) durations from a rocprofv3 --kernel-trace CSV.
 
-rocprofv3's own --stats table merges all dispatches of a kernel; bench.py launches k_striped on class C
-(grid 256000 threads) and, for the scale_ref point, on class D (grid ~3.0 M), so the summary is split
-by grid size here.   python tools/trace_summary.py <..._kernel_trace.csv>  > profiles/<name>.csv
+rocprofv3's own --stats table merges all dispatches of a kernel; bench.py launches k_striped on class C and,
+for the scale_ref point, on class D -- since round 2 with the same grid (256 workgroups of 1024: one per CU), so
+the summary is split by grid size AND, within one (kernel, grid), into groups of dispatches whose durations lie
+more than a factor of three apart (class C ~72 us, class D ~1280 us).
+    python tools/trace_summary.py <..._kernel_trace.csv>  > profiles/<name>.csv
 """
 import csv
 import re
@@ -22,8 +24,17 @@ def main():
     w = csv.writer(sys.stdout)
     w.writerow(["kernel", "grid_threads", "workgroup", "calls", "avg_us", "median_us", "min_us", "max_us", "total_ms"])
     rows = []
-    for (name, grid, wg), v in acc.items():
+    groups = []
+    for key, v in acc.items():
         v.sort()
+        cur = [v[0]]
+        for d in v[1:]:
+            if d > 3.0 * cur[-1]:  # a gap of more than 3x: another workload on the same kernel and grid
+                groups.append((key, cur))
+                cur = []
+            cur.append(d)
+        groups.append((key, cur))
+    for (name, grid, wg), v in groups:
         rows.append((sum(v), [name, grid, wg, len(v), "%.3f" % (sum(v) / len(v)), "%.3f" % v[len(v) // 2],
                               "%.3f" % v[0], "%.3f" % v[-1], "%.3f" % (sum(v) / 1000.0)]))
     for _, row in sorted(rows, reverse=True):
