@@ -66,6 +66,8 @@ typedef struct spmv_hip_stats {
     double t_kernel;        /* s: per-call kernel(s), host-observed                          */
     double t_y_d2h;         /* s: per-call y download      (libspmv/gpu.c:285)               */
     double t_total;         /* s: entry -> return, all calls                                 */
+    int64_t host_calls;     /* of `calls`: products dispatched to the host loop (SPMV_HIP_DISPATCH) */
+    double t_host;          /* s: spent in those                                             */
 } spmv_hip_stats;
 
 /* ---- runtime ------------------------------------------------------------- */

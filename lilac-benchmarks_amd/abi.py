@@ -34,6 +34,7 @@ class Stats(ctypes.Structure):
         ("calls", ctypes.c_int64), ("uploads", ctypes.c_int64), ("invalidations", ctypes.c_int64),
         ("t_init", ctypes.c_double), ("t_upload", ctypes.c_double), ("t_x_h2d", ctypes.c_double),
         ("t_kernel", ctypes.c_double), ("t_y_d2h", ctypes.c_double), ("t_total", ctypes.c_double),
+        ("host_calls", ctypes.c_int64), ("t_host", ctypes.c_double),
     ]
 
     def as_dict(self):

@@ -29,6 +29,12 @@ class CsrF(ctypes.Structure):
                 np.ctypeslib.as_array(self.a, (max(self.nnz, 1),))[: self.nnz])
 
 
+class PsNet(ctypes.Structure):
+    """struct ps_net (host/callers.h): PATHSAMPLE's per-minimum neighbour lists."""
+    _fields_ = [("nmin", ctypes.c_int), ("maxcol", ctypes.c_int), ("ncol", c_int_p), ("nval", c_int_p),
+                ("dmat", ctypes.POINTER(ctypes.c_double))]
+
+
 _lib = None
 
 
@@ -56,6 +62,11 @@ def lib():
         L.mm_read_csr.argtypes = [ctypes.c_char_p, P(CsrD)]
         L.graph_rmat.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, P(CsrD)]
         L.graph_grid2d.argtypes = [ctypes.c_int, ctypes.c_int, P(CsrD)]
+        L.ps_generate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, P(PsNet)]
+        L.ps_free.argtypes = [P(PsNet)]
+        L.ps_free.restype = None
+        L.ps_committor.argtypes = [P(PsNet), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, P(ctypes.c_double)]
+        L.ps_committor.restype = ctypes.c_int64
         L.csr_d_free.argtypes = [P(CsrD)]
         L.csr_d_free.restype = None
         L.csr_f_free.argtypes = [P(CsrF)]
@@ -124,6 +135,26 @@ def pagerank(m, harness_fn, iters, d=0.85, prepare=True):
     x = np.full(m.rows + 2, 1.0 / m.rows)
     err = lib().pagerank_run(ctypes.byref(m), harness_fn, d, iters, x.ctypes.data)
     return x[: m.rows], err
+
+
+def ps_generate(nmin, maxcol=12, seed=38):
+    n = PsNet()
+    _chk(lib().ps_generate(nmin, maxcol, seed, ctypes.byref(n)), "ps_generate")
+    return n
+
+
+def ps_committor(net, harness_fn, npfold, variant):
+    """variant 0: PFOLD (Pfold.f90:219-223, the `a` array rewritten before every call); 1: NGT (NGT.f:999-1002)."""
+    gp = np.zeros(net.nmin)
+    t = ctypes.c_double(0)
+    nnz = lib().ps_committor(ctypes.byref(net), harness_fn, npfold, variant, gp.ctypes.data, ctypes.byref(t))
+    if nnz < 0:
+        raise RuntimeError("ps_committor failed with %d" % nnz)
+    return dict(gpfold=gp, nnz=int(nnz), t_calls=t.value)
+
+
+def ps_free(net):
+    lib().ps_free(ctypes.byref(net))
 
 
 def mm_read(path):

@@ -31,7 +31,8 @@
  *          SURVEY.md 5.2(a)), through pinned staging buffers.
  *   errors: assert -> abort (gpu.c:42-58)
  *       -> message on stderr + abort().  There is no CPU fallback: without a
- *          GPU the first call aborts.
+ *          GPU the first call aborts (tiny products run on the host by choice,
+ *          see SPMV_HIP_DISPATCH, but only on a machine that has the GPU).
  *
  * Environment (read once, at the first call):
  *   SPMV_HIP_CACHE   = mprotect (default) | compare | pointer | off
@@ -54,6 +55,12 @@
  *                      recognised with dladdr) are pinned in place once, everything else goes
  *                      through pinned staging buffers; register: pin whatever the caller passes
  *                      (only safe if the caller never frees it); pageable: plain hipMemcpy
+ *   SPMV_HIP_DISPATCH = auto (default) | device | host
+ *                      auto: a product the host finishes sooner than a PCIe round trip goes to a plain sequential loop in
+ *                      this library (dispatch_host below; precedent: libspmv/mkl.c:30, mkl-model.c:152-165), and the HIP
+ *                      context is not created before a matrix is worth it; device / host force one side.  A machine
+ *                      without a GPU aborts at the first call whatever this says: the host loop is a dispatch target on
+ *                      a GPU machine, not a fallback.
  *   SPMV_HIP_STATS   = 1: summary on stderr at exit; 2: also synchronise
  *                      between the phases of every call to attribute time
  *   SPMV_HIP_VERBOSE = 1: log uploads / invalidations
@@ -80,6 +87,7 @@
 enum { CACHE_MPROTECT = 0, CACHE_POINTER = 1, CACHE_OFF = 2, CACHE_COMPARE = 3 };
 #define MIN_PROTECT_PAGES 64 /* arrays with fewer whole pages are compared byte for byte instead */
 enum { PIN_STAGING = 0, PIN_REGISTER = 1, PIN_PAGEABLE = 2, PIN_AUTO = 3 };
+enum { DISPATCH_AUTO = 0, DISPATCH_DEVICE = 1, DISPATCH_HOST = 2 };
 
 /* one guarded host array: [p, p+bytes) */
 typedef struct guard {
@@ -110,10 +118,14 @@ typedef struct slot {
     volatile sig_atomic_t armed;
     volatile sig_atomic_t dirty;
     uint64_t last_use;
+    int64_t uses;            /* products this copy has served                            */
 } slot;
 
 static struct {
-    int inited;
+    int inited;      /* environment read, GPU presence checked                        */
+    int dev_inited;  /* HIP runtime initialised, device context exists                 */
+    int dispatch;    /* DISPATCH_AUTO / _DEVICE / _HOST                                */
+    double host_spent; /* seconds this process has spent in host products so far       */
     int cache, pin, stats, verbose, zero_copy;
     int plan, plan_param;
     int ndev, nparts, nslots;
@@ -138,31 +150,48 @@ static struct {
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 
 /*
- * Matrices that keep changing (the caller rewrites an array between calls, as PATHSAMPLE's argument
- * order does, Pfold.f90:219-223): the second time the same three pointers are caught changed, their
- * uploads stop asking for a re-laid-out plan -- STRIPED costs 0.1 s per upload of a class-C-sized
- * matrix and pays off only over hundreds of products.  Forgotten at spmv_hip_release().
+ * Matrices that keep changing (the caller rewrites an array between calls, as PATHSAMPLE's argument order does,
+ * Pfold.f90:219-223).  A device copy that is caught changed after serving fewer than SHORT_LIVED_USES products was
+ * "short-lived"; two short-lived copies of the same three pointers in a row make the matrix CHURNING, and then
+ *   - its uploads stop asking for a re-laid-out plan (STRIPED costs 0.1 s per upload of a class-C-sized matrix and pays
+ *     off only over hundreds of products);
+ *   - its arrays are no longer page-protected but compared byte for byte: the runtime's copy leaves the caller's pages
+ *     registered with the GPU driver, and every mprotect() of registered pages makes the driver evict and restore the
+ *     process's queues -- 30 ms for the next copy and 30 ms for the next free, measured with the PATHSAMPLE counterpart
+ *     (profiles/r02_pathsample_driver.log: 60 ms per call, against 5 ms with byte comparison);
+ *   - under SPMV_HIP_DISPATCH=auto the product runs on the host loop whenever that is faster than another upload; every
+ *     CHURN_PROBE_CALLS-th call tries the device again, so a matrix that has stopped changing gets its device copy back.
+ * A copy that serves SHORT_LIVED_USES products or more ends the churning.  Forgotten at spmv_hip_release().
  */
 #define MAX_CHURN 16
-static struct {
+#define SHORT_LIVED_USES 3
+#define CHURN_PROBE_CALLS 64
+typedef struct churn_entry {
     const void *a, *rowstr, *colidx;
-    int count;
-} g_churn[MAX_CHURN];
+    int short_lived;      /* consecutive short-lived copies                                     */
+    int host_streak;      /* host products since the last upload (auto dispatch)                */
+    double last_upload_s; /* what the last upload of these arrays cost                          */
+} churn_entry;
+static churn_entry g_churn[MAX_CHURN];
 static int g_nchurn;
 
-static int churn_note(const void *a, const void *rowstr, const void *colidx, int bump)
+static churn_entry *churn_find(const void *a, const void *rowstr, const void *colidx, int create)
 {
     for (int i = 0; i < g_nchurn; ++i)
-        if (g_churn[i].a == a && g_churn[i].rowstr == rowstr && g_churn[i].colidx == colidx) {
-            g_churn[i].count += bump;
-            return g_churn[i].count;
-        }
-    if (!bump)
-        return 0;
+        if (g_churn[i].a == a && g_churn[i].rowstr == rowstr && g_churn[i].colidx == colidx)
+            return &g_churn[i];
+    if (!create)
+        return NULL;
     const int i = g_nchurn < MAX_CHURN ? g_nchurn++ : 0; /* full: recycle the first entry */
+    memset(&g_churn[i], 0, sizeof g_churn[i]);
     g_churn[i].a = a, g_churn[i].rowstr = rowstr, g_churn[i].colidx = colidx;
-    g_churn[i].count = 1;
-    return 1;
+    return &g_churn[i];
+}
+
+static int churning(const void *a, const void *rowstr, const void *colidx)
+{
+    const churn_entry *e = churn_find(a, rowstr, colidx, 0);
+    return e && e->short_lived >= 2;
 }
 
 static void die(const char *fmt, ...)
@@ -390,10 +419,10 @@ static void print_stats(void)
 {
     const spmv_hip_stats *s = &G.st;
     fprintf(stderr,
-            "libhip-spmv: calls=%lld uploads=%lld invalidations=%lld init=%.3fs upload=%.3fs "
-            "x_h2d=%.3fs kernel=%.3fs y_d2h=%.3fs total=%.3fs\n",
-            (long long)s->calls, (long long)s->uploads, (long long)s->invalidations, s->t_init,
-            s->t_upload, s->t_x_h2d, s->t_kernel, s->t_y_d2h, s->t_total);
+            "libhip-spmv: calls=%lld (host %lld) uploads=%lld invalidations=%lld init=%.3fs upload=%.3fs "
+            "x_h2d=%.3fs kernel=%.3fs y_d2h=%.3fs host=%.3fs total=%.3fs\n",
+            (long long)s->calls, (long long)s->host_calls, (long long)s->uploads, (long long)s->invalidations,
+            s->t_init, s->t_upload, s->t_x_h2d, s->t_kernel, s->t_y_d2h, s->t_host, s->t_total);
 }
 
 void spmv_hip_release(void)
@@ -436,11 +465,19 @@ static void lib_fini(void)
     G.inited = 0;
 }
 
+/* Is there a GPU at all?  Answered without touching the HIP runtime (whose start-up is what small callers
+ * should not pay): the compute driver's device node.  The authoritative check is device_init()'s. */
+static int gpu_node_present(void)
+{
+    const char *fake = getenv("SPMV_HIP_KFD_NODE"); /* tests */
+    return access(fake ? fake : "/dev/kfd", R_OK | W_OK) == 0;
+}
+
+/* first call: the environment, and the refusal to run on a machine without a GPU */
 static void lazy_init(void)
 {
     if (G.inited)
         return;
-    double t0 = spmv_now();
     G.page = sysconf(_SC_PAGESIZE);
     const char *v;
 
@@ -485,6 +522,17 @@ static void lazy_init(void)
         else if (strcmp(v, "auto"))
             die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped", v);
     }
+    G.dispatch = DISPATCH_AUTO;
+    if ((v = getenv("SPMV_HIP_DISPATCH"))) {
+        if (!strcmp(v, "device"))
+            G.dispatch = DISPATCH_DEVICE;
+        else if (!strcmp(v, "host"))
+            G.dispatch = DISPATCH_HOST;
+        else if (strcmp(v, "auto"))
+            die("SPMV_HIP_DISPATCH=%s: expected auto|device|host", v);
+    }
+    if (G.dispatch == DISPATCH_AUTO && (G.plan != SPMV_HIP_PLAN_AUTO || getenv("SPMV_HIP_PARTS") || getenv("SPMV_HIP_DEVICES")))
+        G.dispatch = DISPATCH_DEVICE; /* who names a kernel or a row partition wants the device */
     G.zero_copy = env_int("SPMV_HIP_ZEROCOPY", 1);
     G.stats = env_int("SPMV_HIP_STATS", 0);
     G.verbose = env_int("SPMV_HIP_VERBOSE", 0);
@@ -493,7 +541,19 @@ static void lazy_init(void)
         G.nslots = 1;
     if (G.nslots > MAX_SLOTS)
         G.nslots = MAX_SLOTS;
+    if (!gpu_node_present())
+        die("no HIP device is visible (this backend has no CPU fallback)");
+    atexit(lib_fini);
+    G.inited = 1;
+}
 
+/* first product that goes to the device: the HIP runtime, the context, the code object */
+static void device_init(void)
+{
+    if (G.dev_inited)
+        return;
+    double t0 = spmv_now();
+    const char *v;
     int visible = spmv_hip_device_count();
     if (visible <= 0)
         die("no HIP device is visible (this backend has no CPU fallback)");
@@ -513,9 +573,77 @@ static void lazy_init(void)
     if (!probe)
         die("device initialisation failed: %s", spmv_hip_last_error());
     spmv_hip_free(0, probe);
-    atexit(lib_fini);
-    G.inited = 1;
+    G.dev_inited = 1;
     G.st.t_init = spmv_now() - t0;
+}
+
+/* ---------------------------------------------------------------- host / device dispatch */
+
+/*
+ * The arithmetic of libspmv/native-impl.c:1-25 as it stands there: one accumulator, the product rounded
+ * before the add (this file is compiled with -ffp-contract=off), left to right.  Results are bit-identical to
+ * the reference's CPU backend.  It exists because a product of a few thousand nonzeros takes the host a few
+ * microseconds and a PCIe round trip twenty (profiles/r01_xferbench_pcie_round_trip.log), and because creating
+ * the HIP context costs 0.2 s, more than the whole run of parboil's or a small graph's caller
+ * (profiles/r01_reference_programs_native_vs_hip.log): the reference's MKL backend makes the same per-call
+ * choice between its native loop and the library (libspmv/mkl.c:30, mkl-model.c:152-165).
+ */
+static void host_spmv_f64(double *ov, const double *a, const double *iv, const int *rowstr, const int *colidx, int rows)
+{
+    for (int i = 0; i < rows; ++i) {
+        double value = 0.0;
+        for (int j = rowstr[i] - 1; j < rowstr[i + 1] - 1; ++j)
+            value += a[j] * iv[colidx[j] - 1];
+        ov[i] = value;
+    }
+}
+
+static void host_spmv_f32(float *ov, const float *a, const float *iv, const int *rowstr, const int *colidx, int rows)
+{
+    for (int i = 0; i < rows; ++i) {
+        float value = 0.0f;
+        for (int j = rowstr[i] - 1; j < rowstr[i + 1] - 1; ++j)
+            value += a[j] * iv[colidx[j] - 1];
+        ov[i] = value;
+    }
+}
+
+/* seconds: the host loop streams about a nonzero per nanosecond while the matrix fits the caches (native.c on the
+ * GPU box's EPYC: 2.1 GFLOP/s on class C, out of cache) */
+static double host_estimate(int rows, int64_t nnz) { return 1.0e-9 * (double)nnz + 1.0e-9 * (double)rows + 0.2e-6; }
+
+/* seconds for a device call once the matrix is cached: the PCIe round trip of x and y (19 us zero-copy under 1 MB, DMA
+ * at ~25 GB/s each way above) plus a kernel that streams 12 bytes per nonzero at a few TB/s */
+static double device_estimate(int rows, int64_t nnz, int elem)
+{
+    const double vec = 2.0 * (double)rows * elem; /* x and y; cols is not known before the upload: square */
+    return 19.0e-6 + (vec > 2.0e6 ? vec / 25.0e9 : 0.0) + 5.0e-6 + (double)nnz * (elem + 4) / 3.0e12;
+}
+
+/*
+ * Before the HIP context exists, going to the device costs its creation on top (0.15-0.2 s): a process stays on the
+ * host until it has spent about half of that there (the ski-rental rule: never more than ~1.5x the better choice),
+ * unless the matrix is plainly device-class -- from about 1.5 M nonzeros a few dozen products repay the context (NPB
+ * class A, 1.85 M: 416 calls, 0.21 s on the device against 0.55 s on the host).  Below that lie the callers whose whole
+ * run is shorter than the context creation: parboil's datasets (0.07 / 2.9 ms for 50 products), BFS on a 2^16-vertex
+ * graph (44 ms for 16 searches), NPB class S (16 ms).
+ */
+#define HOST_BUDGET_BEFORE_INIT 0.100 /* s of host products before a process pays for the HIP context              */
+#define DEVICE_CLASS_SECONDS 1.5e-3   /* est. host time per product from which the device is taken at once          */
+
+/* 1: this call runs on the host */
+static int dispatch_host(int rows, int64_t nnz, int elem)
+{
+    if (G.dispatch == DISPATCH_HOST)
+        return 1;
+    if (G.dispatch == DISPATCH_DEVICE)
+        return 0;
+    const double th = host_estimate(rows, nnz);
+    if (th <= device_estimate(rows, nnz, elem))
+        return 1; /* steady state: the host is done before x would have crossed PCIe */
+    if (!G.dev_inited && th < DEVICE_CLASS_SECONDS && G.host_spent + th < HOST_BUDGET_BEFORE_INIT)
+        return 1; /* not worth the 0.2 s of context creation yet */
+    return 0;
 }
 
 static slot *slot_find(const void *a, const int *rowstr, const int *colidx, int rows, int64_t nnz,
@@ -611,8 +739,8 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
     sl->nparts = G.nparts > rows ? (rows > 0 ? rows : 1) : G.nparts;
     spmv_hip_partition_rows(rowstr, rows, sl->nparts, sl->bounds);
 
-    const int churning = G.cache == CACHE_OFF || churn_note(a, rowstr, colidx, 0) >= 2;
-    spmvd_set_relayout(!churning);
+    const int churn = G.cache == CACHE_OFF || churning(a, rowstr, colidx);
+    spmvd_set_relayout(!churn);
     /* the length of x: max(colidx) over the WHOLE matrix (libspmv/gpu.c:217-223); one part finds it on the device
      * while it uploads, several parts need it up front so that they can upload side by side */
     int cols = 0;
@@ -657,7 +785,8 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
 
     /* arm write detection AFTER the upload (the copies read the arrays) */
     if (G.cache != CACHE_OFF) {
-        const int protect = G.cache == CACHE_MPROTECT ? 1 : (G.cache == CACHE_COMPARE ? 2 : 0);
+        /* a churning matrix is compared, not protected: see the note at g_churn */
+        const int protect = G.cache == CACHE_MPROTECT ? (churn ? 2 : 1) : (G.cache == CACHE_COMPARE ? 2 : 0);
         const size_t off = (size_t)(rowstr[0] - 1);
         const void *ptrs[3] = {(const char *)a + off * elem, rowstr, colidx + off};
         const size_t lens[3] = {(size_t)nnz * elem, ((size_t)rows + 1) * sizeof(int),
@@ -683,6 +812,11 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
     }
     G.st.uploads++;
     G.st.t_upload += spmv_now() - t0;
+    {
+        churn_entry *e = churn_find(a, rowstr, colidx, 0);
+        if (e)
+            e->last_upload_s = spmv_now() - t0, e->host_streak = 0;
+    }
     if (G.verbose) {
         spmv_hip_info inf;
         spmv_hip_matrix_info(sl->part[0], &inf);
@@ -883,6 +1017,19 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
         return NULL;
     }
     lazy_init();
+    if (dispatch_host(rows, nnz, elem)) {
+        if (elem == 8)
+            host_spmv_f64((double *)ov, (const double *)a, (const double *)iv, rowstr, colidx, rows);
+        else
+            host_spmv_f32((float *)ov, (const float *)a, (const float *)iv, rowstr, colidx, rows);
+        const double dt = spmv_now() - t_in;
+        G.host_spent += dt;
+        G.st.calls++, G.st.host_calls++;
+        G.st.t_host += dt, G.st.t_total += dt;
+        pthread_mutex_unlock(&g_mu);
+        return NULL;
+    }
+    device_init();
 
     slot *sl = slot_find(a, rowstr, colidx, rows, nnz, elem);
     if (sl) {
@@ -893,19 +1040,50 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
         if (stale) {
             if (G.cache != CACHE_OFF) {
                 G.st.invalidations++;
-                churn_note(a, rowstr, colidx, 1);
+                churn_entry *e = churn_find(a, rowstr, colidx, 1);
+                e->short_lived = sl->uses < SHORT_LIVED_USES ? e->short_lived + 1 : 0;
                 if (G.verbose)
                     fprintf(stderr, "libhip-spmv: host arrays changed, dropping the device copy\n");
             }
+            const double td = spmv_now();
             slot_drop(sl);
+            if (G.verbose >= 2)
+                fprintf(stderr, "libhip-spmv: dropped the stale copy in %.3f ms\n", 1e3 * (spmv_now() - td));
             sl = NULL;
         }
     }
+    if (!sl && G.dispatch == DISPATCH_AUTO && G.nparts == 1) {
+        /* a churning matrix: the host loop, unless another upload is the faster way or it is time to look again */
+        churn_entry *e = churn_find(a, rowstr, colidx, 0);
+        if (e && e->short_lived >= 2 && e->host_streak < CHURN_PROBE_CALLS &&
+            host_estimate(rows, nnz) <= e->last_upload_s + device_estimate(rows, nnz, elem)) {
+            e->host_streak++;
+            if (elem == 8)
+                host_spmv_f64((double *)ov, (const double *)a, (const double *)iv, rowstr, colidx, rows);
+            else
+                host_spmv_f32((float *)ov, (const float *)a, (const float *)iv, rowstr, colidx, rows);
+            const double dt = spmv_now() - t_in;
+            G.host_spent += dt;
+            G.st.calls++, G.st.host_calls++;
+            G.st.t_host += dt, G.st.t_total += dt;
+            pthread_mutex_unlock(&g_mu);
+            return NULL;
+        }
+    }
     if (!sl) {
+        const double tu = spmv_now();
         sl = slot_victim();
         slot_upload(sl, a, rowstr, colidx, rows, nnz, elem);
+        if (G.verbose >= 2)
+            fprintf(stderr, "libhip-spmv: victim + upload + arm in %.3f ms\n", 1e3 * (spmv_now() - tu));
     }
     sl->last_use = ++G.tick;
+    sl->uses++;
+    if (sl->uses == SHORT_LIVED_USES) { /* this copy has lived: whatever churned before has stopped */
+        churn_entry *e = churn_find(a, rowstr, colidx, 0);
+        if (e)
+            e->short_lived = 0;
+    }
     G.last = sl;
 
     const size_t xbytes = (size_t)sl->cols * elem;

@@ -98,6 +98,17 @@ int sb_read_crs(const char *path, csr_d *out)
             csr_d_free(out);
             return -2;
         }
+    if (out->rowstr[0] != 1 || out->rowstr[n] != nnz + 1) {
+        fclose(f);
+        csr_d_free(out);
+        return -2; /* the header and the row pointers disagree (gen_crs.f:768-772 stops with "Strange crs read error") */
+    }
+    for (long i = 0; i < n; ++i)
+        if (out->rowstr[i + 1] < out->rowstr[i]) {
+            fclose(f);
+            csr_d_free(out);
+            return -2;
+        }
     /* gen_crs.f:775-785: the entries are read in stream order, exactly nnz of them */
     for (long j = 0; j < nnz; ++j) {
         if (fscanf(f, "%d %lf", &out->colidx[j], &out->a[j]) != 2 || out->colidx[j] < 1 || out->colidx[j] > n) {
@@ -679,6 +690,103 @@ int mm_read_csr(const char *path, csr_d *out)
     }
     free(ri), free(ci), free(va), free(pos);
     return 0;
+}
+
+/* ================================= PATHSAMPLE ================================================ */
+
+void ps_free(ps_net *n)
+{
+    free(n->ncol), free(n->nval), free(n->dmat);
+    memset(n, 0, sizeof *n);
+}
+
+int ps_generate(int nmin, int maxcol, uint64_t seed, ps_net *out)
+{
+    memset(out, 0, sizeof *out);
+    if (nmin < 2 || maxcol < 1)
+        return -2;
+    if (maxcol > nmin - 1)
+        maxcol = nmin - 1;
+    out->nmin = nmin, out->maxcol = maxcol;
+    out->ncol = malloc((size_t)nmin * sizeof(int));
+    out->nval = malloc((size_t)nmin * maxcol * sizeof(int));
+    out->dmat = malloc((size_t)nmin * maxcol * sizeof(double));
+    if (!out->ncol || !out->nval || !out->dmat) {
+        ps_free(out);
+        return -3;
+    }
+    rng r = {seed * 0x9E3779B97F4A7C15ull + 38, 0, 0.0};
+    for (int j1 = 0; j1 < nmin; ++j1) {
+        int nc = 1 + (int)(rng_u64(&r) % (uint64_t)maxcol);
+        int *v = out->nval + (size_t)j1 * maxcol;
+        double *d = out->dmat + (size_t)j1 * maxcol, sum = 0.0;
+        for (int j2 = 0; j2 < nc; ++j2) { /* distinct neighbours, not the minimum itself */
+            int c;
+            int again;
+            do {
+                c = 1 + (int)(rng_u64(&r) % (uint64_t)nmin);
+                again = c == j1 + 1;
+                for (int k = 0; k < j2 && !again; ++k)
+                    again = v[k] == c;
+            } while (again);
+            v[j2] = c;
+            d[j2] = 0.05 + rng_uniform(&r);
+            sum += d[j2];
+        }
+        for (int j2 = 0; j2 < nc; ++j2)
+            d[j2] *= 0.98 / sum; /* branching probabilities: the rest is the self-return */
+        out->ncol[j1] = nc;
+    }
+    return 0;
+}
+
+int64_t ps_committor(const ps_net *n, d_harness_fn spmv, int npfold, int variant, double *gpfold, double *t_calls)
+{
+    const int nmin = n->nmin;
+    /* Pfold.f90:193-211 / NGT.f:976-996: compressed row storage from the neighbour lists */
+    int64_t nonzero = 0;
+    for (int j1 = 0; j1 < nmin; ++j1)
+        nonzero += n->ncol[j1];
+    const size_t len = (size_t)(nonzero > nmin ? nonzero : nmin) + 2; /* swapped roles: see callers.h */
+    double *dvec = calloc(len, sizeof(double)), *newpfold = calloc(len, sizeof(double));
+    double *gp = calloc((size_t)nmin + 2, sizeof(double));
+    int *col_ind = malloc((size_t)(nonzero ? nonzero : 1) * sizeof(int)), *row_ptr = malloc(((size_t)nmin + 1) * sizeof(int));
+    if (!dvec || !newpfold || !gp || !col_ind || !row_ptr) {
+        free(dvec), free(newpfold), free(gp), free(col_ind), free(row_ptr);
+        return -3;
+    }
+    int64_t ncount = 0;
+    int ncolprev = 0;
+    row_ptr[0] = 1;
+    for (int j1 = 0; j1 < nmin; ++j1) {
+        if (j1 > 0)
+            row_ptr[j1] = row_ptr[j1 - 1] + ncolprev;
+        ncolprev = n->ncol[j1];
+        for (int j2 = 0; j2 < n->ncol[j1]; ++j2) {
+            dvec[ncount] = n->dmat[(size_t)j1 * n->maxcol + j2];
+            col_ind[ncount] = n->nval[(size_t)j1 * n->maxcol + j2];
+            ++ncount;
+        }
+    }
+    row_ptr[nmin] = (int)(nonzero + 1);
+    /* initial committor values: 1 for the "A" minima (here: the first tenth), 0 elsewhere */
+    for (int j = 0; j < nmin; ++j)
+        gp[j] = j < (nmin + 9) / 10 ? 1.0 : 0.0;
+    memcpy(newpfold, gp, (size_t)nmin * sizeof(double)); /* NEWPFOLD(1:NMIN)=GPFOLD(1:NMIN) */
+    double t = 0.0;
+    for (int j1 = 0; j1 < npfold; ++j1) {
+        int rows = nmin - 1; /* the temporary NMIN-1 */
+        double t0 = now_s();
+        spmv(gp, newpfold, dvec, row_ptr, col_ind, &rows); /* Pfold.f90:221, NGT.f:1001 */
+        t += now_s() - t0;
+        if (variant == 0)
+            memcpy(newpfold, gp, (size_t)nmin * sizeof(double)); /* Pfold.f90:222 */
+    }
+    memcpy(gpfold, gp, (size_t)nmin * sizeof(double));
+    if (t_calls)
+        *t_calls = t;
+    free(dvec), free(newpfold), free(gp), free(col_ind), free(row_ptr);
+    return nonzero;
 }
 
 /* ================================= seeded graphs ============================================== */

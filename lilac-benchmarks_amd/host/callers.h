@@ -83,6 +83,33 @@ int pb_compare(const float *ref, const float *cmp, int n);
 /* src/cpu/main.c:93-95: reps x f_spmv_harness_. */
 void pb_run(const csr_f *m, f_harness_fn spmv, float *x, float *y, int reps);
 
+/* ---- PATHSAMPLE ----------------------------------------------------- */
+/*
+ * The committor iteration of wales/PATHSAMPLE: Pfold.f90:190-225 (PFOLD) and NGT.f:976-1003 (NGT).  Both build a CRS
+ * matrix from per-minimum neighbour lists (NVAL(J2,J1), values DMATMC / PBRANCH(J2,J1), NCOL(J1) neighbours of minimum
+ * J1: Pfold.f90:193-211) and then make NPFOLD identical calls
+ *     CALL SPMV_HARNESS(GPFOLD, NEWPFOLD, DVEC, ROW_PTR, COL_IND, NMIN-1)
+ * -- `rows` is the temporary NMIN-1 (one row fewer than ROW_PTR describes), and NEWPFOLD / DVEC sit in the ABI's `a` /
+ * `iv` positions, i.e. swapped against native.c:3 (ov, a, iv, ...): the backend sees the VECTOR as the value array
+ * (indexed by nonzero) and the matrix values as x (indexed by column).  PFOLD then copies GPFOLD over NEWPFOLD
+ * (Pfold.f90:222), so the array in the `a` position changes before every call; NGT does not, so nothing changes
+ * between its calls.  Our arrays are sized so that the swapped roles stay inside allocated memory (the Fortran reads
+ * NEWPFOLD beyond NMIN; here those entries exist and are 0).
+ */
+typedef struct ps_net {
+    int nmin, maxcol;
+    int *ncol;    /* [nmin]            NCOL(J1)                  */
+    int *nval;    /* [nmin * maxcol]   NVAL(J2,J1), 1-based ids  */
+    double *dmat; /* [nmin * maxcol]   DMATMC / PBRANCH(J2,J1)   */
+} ps_net;
+/* seeded stand-in for MAKED2's output (the LJ38 database, min.data / ts.data, is not in the repository): every minimum
+ * gets 1..maxcol distinct neighbours and branching probabilities that sum to < 1 */
+int ps_generate(int nmin, int maxcol, uint64_t seed, ps_net *out);
+void ps_free(ps_net *n);
+/* variant 0 = PFOLD (NEWPFOLD = GPFOLD after every call), 1 = NGT (no copy).  gpfold[nmin] receives the final GPFOLD;
+ * *t_calls the seconds spent inside the npfold calls.  Returns the number of nonzeros, < 0 on error. */
+int64_t ps_committor(const ps_net *n, d_harness_fn spmv, int npfold, int variant, double *gpfold, double *t_calls);
+
 /* ---- Matrix Market (generic) -------------------------------------------------------------- */
 /* coordinate real/integer/pattern, general/symmetric -> 1-based CSR of doubles (pattern: 1.0). */
 int mm_read_csr(const char *path, csr_d *out);

@@ -7,6 +7,7 @@
  *   spmvdrv bfs      <backend.so> <pairs file | rmat:SCALE:EF | grid:N> [sources]
  *   spmvdrv pagerank <backend.so> <file.mtx | rmat:SCALE:EF | grid:N> [iters] [runs]
  *   spmvdrv parboil  <backend.so> <matrix.mtx> <vector.bin> [out file] [golden .out]
+ *   spmvdrv pathsample <backend.so> <nmin> [npfold] [max neighbours] [seed]
  *
  * The backend is loaded like pagerank/main.cpp:13-45 does (dlopen RTLD_NOW + dlsym).
  */
@@ -63,7 +64,7 @@ static int load_graph(const char *spec, csr_d *m, int as_bfs)
 int main(int argc, char **argv)
 {
     if (argc < 4) {
-        fprintf(stderr, "Usage: %s sb|bfs|pagerank|parboil <backend.so> <input> [...]\n", argv[0]);
+        fprintf(stderr, "Usage: %s sb|bfs|pagerank|parboil|pathsample <backend.so> <input> [...]\n", argv[0]);
         return 1;
     }
     const char *bench = argv[1];
@@ -192,6 +193,30 @@ int main(int argc, char **argv)
         csr_f_free(&m);
         if (bad > 0)
             return 6;
+    } else if (!strcmp(bench, "pathsample")) {
+        const int nmin = atoi(argv[3]), npfold = argc > 4 ? atoi(argv[4]) : 100;
+        ps_net net;
+        int rc = ps_generate(nmin, argc > 5 ? atoi(argv[5]) : 12, argc > 6 ? strtoull(argv[6], 0, 10) : 38, &net);
+        if (rc) {
+            fprintf(stderr, "cannot make a network of %d minima: %d\n", nmin, rc);
+            return 4;
+        }
+        double *gp = malloc(((size_t)nmin + 2) * sizeof(double));
+        printf("%s,PATHSAMPLE,%s,%d", platform, impl, nmin);
+        for (int variant = 0; variant < 2; ++variant) { /* PFOLD (Pfold.f90:219-223), then NGT (NGT.f:999-1002) */
+            double t = 0.0;
+            const int64_t nnz = ps_committor(&net, dfn, npfold, variant, gp, &t);
+            if (nnz < 0)
+                return 4;
+            printf(",%.6f", t);
+            fprintf(stderr, "%s: nmin=%d nonzero=%lld npfold=%d  %.2f us per call  gpfold_fnv=%016llx\n",
+                    variant ? "NGT   (nothing changes between calls)" : "PFOLD (the `a` array rewritten before every call)",
+                    nmin, (long long)nnz, npfold, 1e6 * t / (npfold > 0 ? npfold : 1),
+                    (unsigned long long)fnv(gp, (size_t)nmin * sizeof(double)));
+        }
+        printf("\n");
+        free(gp);
+        ps_free(&net);
     } else {
         fprintf(stderr, "unknown benchmark %s\n", bench);
         return 1;

@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# The ABI dispatches tiny products to a host loop (SPMV_HIP_DISPATCH=auto); the parity tests are about the HIP path, so
+# the session forces the device unless a test says otherwise (tests of the dispatch run in fresh processes).
+os.environ.setdefault("SPMV_HIP_DISPATCH", "device")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

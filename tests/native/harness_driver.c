@@ -64,10 +64,60 @@ static void check(const csr *m, const double *x, const double *y)
     }
 }
 
+/* SPMV_HIP_DISPATCH=auto: tiny products on the host loop, bit-identical to native-impl.c; a mid-size matrix on
+ * the host until the process has spent its budget there, then on the device; a large one on the device at once */
+static int dispatch_scenario(void)
+{
+    spmv_hip_stats s;
+    {
+        csr m = make(300, 300, 3);
+        double *x = (double *)malloc(300 * sizeof(double)), *y = (double *)malloc(300 * sizeof(double));
+        for (int i = 0; i < 300; ++i)
+            x[i] = rnd();
+        int rows = m.rows;
+        for (int k = 0; k < 5; ++k)
+            spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
+        check(&m, x, y);
+        spmv_hip_get_stats(&s);
+        EXPECT(s.calls == 5 && s.host_calls == 5 && s.uploads == 0 && mock_creates == 0);
+        free(m.rowstr), free(m.colidx), free(m.a), free(x), free(y);
+    }
+    {
+        csr m = make(20000, 20000, 25); /* 500 000 nonzeros: ~0.5 ms on the host, more than a PCIe round trip */
+        double *x = (double *)malloc(20000 * sizeof(double)), *y = (double *)malloc(20000 * sizeof(double));
+        for (int i = 0; i < 20000; ++i)
+            x[i] = rnd();
+        int rows = m.rows, n = 0;
+        do {
+            spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
+            check(&m, x, y);
+            spmv_hip_get_stats(&s);
+            ++n;
+        } while (s.uploads == 0 && n < 100000);
+        EXPECT(s.uploads == 1 && mock_creates == 1); /* the budget ran out: the context was "created", the matrix uploaded */
+        EXPECT(s.host_calls >= 2 && s.t_host >= 0.08 && s.t_host < 1.5); /* about 100 ms of host products (sanitizers stretch a call) */
+        const long long host_before = (long long)s.host_calls;
+        spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
+        spmv_hip_get_stats(&s);
+        EXPECT((long long)s.host_calls == host_before && s.uploads == 1); /* stays on the device, cached */
+        /* a tiny product still goes to the host: the PCIe round trip has not become cheaper */
+        int few = 40;
+        spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &few);
+        spmv_hip_get_stats(&s);
+        EXPECT((long long)s.host_calls == host_before + 1);
+        spmv_hip_release();
+        free(m.rowstr), free(m.colidx), free(m.a), free(x), free(y);
+    }
+    printf("ok host / device dispatch\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const char *policy = argc > 1 ? argv[1] : "mprotect";
     spmv_hip_stats s;
+    if (argc > 2 && !strcmp(argv[2], "dispatch"))
+        return dispatch_scenario();
     csr m = make(6000, 5000, 40); /* a: 1.9 MB, colidx: 960 KB: interior pages get protected */
     double *x = (double *)malloc(5000 * sizeof(double)), *y = (double *)malloc(6000 * sizeof(double));
     for (int i = 0; i < 5000; ++i)

@@ -230,3 +230,63 @@ def test_malformed_files_are_refused_not_indexed(pkg, tmp_path, reader, text):
     fn = {"mm": C.mm_read, "pb": C.pb_load, "bfs": C.bfs_read}[reader]
     with pytest.raises(RuntimeError, match="-2"):
         fn(path)
+
+
+def test_sparsebench_reader_on_a_file_written_by_the_references_generator(pkg, oracle):
+    """tests/golden/sparsebench/crsmat010u was written by the reference's big_gen.py (seeded; make_sb_fixture.py): n = 10^3.
+    Quirk N1: the generator appends the diagonal after row_ptr was built, so the file holds nnz + ~n
+    entry lines while header and row_ptr say nnz; the Fortran reader (gen_crs.f:775-785) -- and ours -- consume the FIRST
+    nnz in stream order.  The rows as read are therefore not the generator's rows: unsorted, shifted -- and that is the
+    matrix the reference's benchmark multiplies with."""
+    C = pkg.callers
+    path = os.path.join(GOLD, "sparsebench", "crsmat010u")
+    lines = open(path).read().splitlines()
+    n, nnz = int(lines[0][:12]), int(lines[0][12:24])  # big_gen.py:53 "{:12}{:12}"
+    assert (n, nnz) == (1000, 4690)
+    ptr = np.array([int(l) for l in lines[1:n + 2]], np.int64)
+    entries = lines[n + 2:]
+    assert ptr[0] == 1 and ptr[-1] == nnz + 1
+    assert nnz + n - 50 < len(entries) < nnz + n + 1  # the surplus: one diagonal per row that did not draw it (993 here)
+    cols = np.array([int(l[:12]) for l in entries[:nnz]], np.int32)  # "{:12} {:20.17f}"
+    vals = np.array([float(l[12:]) for l in entries[:nnz]])
+    m = C.sb_read(path)
+    rs, ci, a = m.arrays()
+    assert m.rows == n and m.nnz == nnz
+    assert np.array_equal(rs, ptr.astype(np.int32)) and np.array_equal(ci, cols) and np.array_equal(a, vals)
+    assert np.any(np.diff(ci)[np.setdiff1d(np.arange(nnz - 1), ptr[1:-1] - 2)] < 0)  # rows as read are NOT sorted
+    x = np.random.default_rng(10).standard_normal(n)
+    y = oracle.spmv(a.copy(), x, rs.copy(), ci.copy(), n)
+    dense = np.zeros((n, n))
+    for r in range(n):
+        for j in range(rs[r] - 1, rs[r + 1] - 1):
+            dense[r, ci[j] - 1] += a[j]
+    assert np.allclose(y, dense @ x, rtol=1e-12, atol=1e-12)
+    C.free(m)
+    # a header that disagrees with the row pointers is refused (gen_crs.f:768-772 stops)
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix="crs", delete=False) as f:
+        f.write("%12d%12d\n" % (n, nnz - 1))
+        f.write("\n".join(lines[1:]))
+    with pytest.raises(RuntimeError, match="-2"):
+        C.sb_read(f.name)
+    os.unlink(f.name)
+
+
+def test_pathsample_counterpart_on_the_oracle(pkg, oracle, reference):
+    """PATHSAMPLE's committor iteration (Pfold.f90:190-225, NGT.f:976-1003): NPFOLD calls with rows = NMIN-1 and the
+    vector in the ABI's `a` position.  On the oracle and on the reference's native.so the two variants must give the same
+    bits, the last minimum (row NMIN, which the call never reaches) must keep its start value, and PFOLD -- which feeds
+    every result back -- must differ from NGT, which repeats one product."""
+    C = pkg.callers
+    net = C.ps_generate(3000, 10, 38)
+    res = {}
+    for variant in (0, 1):
+        a = C.ps_committor(net, oracle.harness_fn(), 30, variant)
+        b = C.ps_committor(net, reference.harness_fn(), 30, variant)
+        assert np.array_equal(a["gpfold"].view(np.uint64), b["gpfold"].view(np.uint64))
+        assert a["nnz"] >= 3000 and a["gpfold"][-1] == 0.0 and np.all(np.isfinite(a["gpfold"]))
+        res[variant] = a["gpfold"]
+    assert not np.array_equal(res[0], res[1])
+    once = C.ps_committor(net, oracle.harness_fn(), 1, 1)["gpfold"]
+    assert np.array_equal(res[1], once)  # NGT: every call computes the same product
+    C.ps_free(net)

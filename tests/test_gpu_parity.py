@@ -450,6 +450,53 @@ def test_abi_policies_in_a_fresh_process(env, uploads, exact):
     assert int(out[4]) == 3000
 
 
+DISPATCH_SCRIPT = """
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, pkgload, matgen
+from oracle.oracle import Oracle
+p = pkgload.load_package(); be = p.Backend(); o = Oracle()
+cases = [("tiny", matgen.random_csr(71, 1100, 1100, 4)), ("small_f32", matgen.random_csr(72, 12000, 12000, 12, np.float32)),
+         ("mid", matgen.npb_like(73, 1400, 56)), ("large", matgen.npb_like(74, 14000, 132))]
+out = []
+for name, (rs, ci, a) in cases:
+    rows = rs.size - 1
+    x = np.random.default_rng(7).standard_normal(rows).astype(a.dtype)
+    y = np.full(rows, np.nan, a.dtype)
+    s0 = be.stats() if out else dict(calls=0, host_calls=0, uploads=0)
+    for _ in range(3):
+        be.harness(y, a, x, rs, ci, rows)
+    s1 = be.stats()
+    ref = o.spmv(a, x, rs, ci, rows); ab = o.absum(a, x, rs, ci, rows)
+    exact = bool(np.array_equal(y.view(np.uint32 if a.dtype == np.float32 else np.uint64), ref.view(np.uint32 if a.dtype == np.float32 else np.uint64)))
+    eps = 2.0**-24 if a.dtype == np.float32 else 2.0**-53
+    close = bool(np.all(np.abs(y.astype(np.float64) - ref) <= (np.diff(rs) + 24.0) * eps * ab))
+    out.append("%%s:%%d:%%d:%%d:%%d" %% (name, s1["host_calls"] - s0["host_calls"], s1["uploads"] - s0["uploads"], int(exact), int(close)))
+print("DISPATCH", " ".join(out), "init=%%.3f" %% be.stats()["t_init"])
+"""
+
+
+@pytest.mark.parametrize("mode", ["auto", "host", "device"])
+def test_host_device_dispatch(mode):
+    """SPMV_HIP_DISPATCH (libspmv/mkl.c:30, mkl-model.c:152-165 is the precedent): under `auto` a product the host finishes
+    before x would have crossed PCIe runs on the library's own sequential loop -- bit-identical to native-impl.c -- and
+    the HIP context is not created before a matrix is worth it (the first three cases never touch the device: no upload, no
+    init time), while an NPB-class-A-sized matrix goes to the device at once; `host` and `device` force a side: the same
+    matrices bit-identical on the host, within the reordering bound on the device."""
+    code = DISPATCH_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__))
+    out = _run_py(code, {"SPMV_HIP_DISPATCH": mode})
+    line = [l for l in out.splitlines() if l.startswith("DISPATCH")][0].split()
+    got = {f.split(":")[0]: [int(v) for v in f.split(":")[1:]] for f in line[1:5]}
+    init = float(line[5].split("=")[1])
+    for name, (host_calls, uploads, exact, close) in got.items():
+        assert close, (mode, name)
+        if mode == "host" or (mode == "auto" and name != "large"):
+            assert host_calls == 3 and uploads == 0 and exact, (mode, name, got[name])
+        else:
+            assert host_calls == 0 and uploads == 1, (mode, name, got[name])
+    assert (init == 0.0) == (mode == "host"), (mode, init)  # the host side never creates the HIP context
+
+
 CLASS_D_SCRIPT = """
 import sys, time
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
@@ -613,6 +660,40 @@ def test_sparsebench_bicg_driver(pkg, backend, oracle):
     C.free(m)
 
 
+BICG_ORDERED_SCRIPT = """
+import sys, os
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, pkgload
+from oracle.oracle import Oracle
+p = pkgload.load_package(); be = p.Backend(); o = Oracle(); C = p.callers
+out = []
+for name, m in (("big_gen_10", C.sb_read(os.path.join(%(tests)r, "golden", "sparsebench", "crsmat010u"))),
+                ("generated_24", C.sb_generate(24, 170))):
+    r0 = C.sb_bicg(m, o.harness_fn()); r1 = C.sb_bicg(m, be.harness_fn())
+    same = r0["its"] == r1["its"] and r0["calls"] == r1["calls"] and bool(np.array_equal(r0["hist"].view(np.uint64), r1["hist"].view(np.uint64)))
+    same = same and bool(np.array_equal(r0["x"].view(np.uint64), r1["x"].view(np.uint64)))
+    out.append("%%s:%%d:%%d:%%d:%%.3e" %% (name, int(same), abs(r0["its"]), r1["calls"], float(np.max(np.abs(r0["hist"])))))
+    C.free(m)
+print("BICG", " ".join(out), be.abi_matrix_info()["plan"], be.stats()["host_calls"])
+"""
+
+
+def test_sparsebench_bicg_history_is_bit_identical_under_the_ordered_plan():
+    """the reference's pseudo-BiCG (both products are A x, SRC/reference/random.f:66-72) diverges on
+    big_gen matrices and amplifies any reordering of a sum -- so with SPMV_HIP_PLAN=ordered (one lane per row, sequential,
+    no FMA) the ENTIRE residual history (SRC/reference/iter.f:18-100, 100 iterations, 201 products) and the final iterate
+    are bit-identical to the run on the oracle, on the file the reference's own generator wrote and on a 13 824-row matrix
+    of ours.  (The AUTO plan is held to the first iterations only, test_sparsebench_bicg_driver.)"""
+    code = BICG_ORDERED_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__))
+    out = _run_py(code, {"SPMV_HIP_PLAN": "ordered"})
+    line = [l for l in out.splitlines() if l.startswith("BICG")][0].split()
+    for f in line[1:3]:
+        name, same, its, calls, biggest = f.split(":")
+        assert int(same) == 1, (name, line)
+        assert int(calls) == 1 + 2 * int(its)
+    assert int(line[3]) == 1 and int(line[4]) == 0  # the ORDERED plan, on the device, every call
+
+
 def test_pathsample_shaped_calls(backend, oracle):
     """wales/PATHSAMPLE/source/Pfold.f90:219-223: NPFOLD calls with rows passed as the temporary
     NMIN-1 (fewer rows than the row pointer array describes), more columns than rows, and one of the
@@ -631,6 +712,64 @@ def test_pathsample_shaped_calls(backend, oracle):
                           np.float64, "pfold call %d" % it)
     s = backend.stats()
     assert s["calls"] == 4 and s["uploads"] == 4  # each rewrite was noticed
+
+
+def test_pathsample_counterpart(pkg, backend, oracle):
+    """host/callers.c ps_committor = PATHSAMPLE's committor iteration (Pfold.f90:190-225, NGT.f:976-1003) on the library:
+    PFOLD rewrites the array in the ABI's `a` position before every call (every call must see the new contents: one
+    upload per call, and after the second change of the same arrays no re-layout any more); NGT changes nothing
+    between its NPFOLD calls (one upload, the cached fast path).  Both against the oracle run."""
+    C = pkg.callers
+    net = C.ps_generate(40000, 12, 38)  # ~260 000 nonzeros: the value array spans > 64 pages, so it is page-protected
+    npfold = 12
+    for variant, name in ((0, "PFOLD"), (1, "NGT")):
+        ref = C.ps_committor(net, oracle.harness_fn(), npfold, variant)
+        backend.release()
+        backend.reset_stats()
+        got = C.ps_committor(net, backend.harness_fn(), npfold, variant)
+        s = backend.stats()
+        assert got["nnz"] == ref["nnz"] and s["calls"] == npfold and s["host_calls"] == 0
+        assert np.allclose(got["gpfold"], ref["gpfold"], rtol=1e-11, atol=1e-300), name
+        assert got["gpfold"][-1] == ref["gpfold"][-1] == 0.0  # row NMIN is never written: rows = NMIN-1
+        if variant == 0:
+            assert s["uploads"] == npfold and s["invalidations"] == npfold - 1, (name, s)
+        else:
+            assert s["uploads"] == 1 and s["invalidations"] == 0, (name, s)
+    backend.release()
+    C.ps_free(net)
+
+
+CHURN_SCRIPT = """
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np, pkgload
+from oracle.oracle import Oracle
+p = pkgload.load_package(); be = p.Backend(); o = Oracle(); C = p.callers
+net = C.ps_generate(400000, 12, 38)
+out = []
+for variant in (0, 1):
+    ref = C.ps_committor(net, o.harness_fn(), 150, variant)
+    be.release(); be.reset_stats()
+    got = C.ps_committor(net, be.harness_fn(), 150, variant)
+    s = be.stats()
+    ok = bool(np.allclose(got["gpfold"], ref["gpfold"], rtol=1e-11, atol=1e-300))
+    out.append("%%d:%%d:%%d:%%d:%%.1f" %% (int(ok), s["calls"], s["host_calls"], s["uploads"], 1e6 * got["t_calls"] / 150))
+print("CHURN", " ".join(out))
+"""
+
+
+def test_a_churning_matrix_goes_to_the_host_loop_under_auto_dispatch():
+    """PATHSAMPLE's PFOLD rewrites the array in the ABI's `a` position before every call (Pfold.f90:219-223): a device copy
+    never serves two products.  Under SPMV_HIP_DISPATCH=auto the third change of the same arrays makes the matrix churning,
+    and from then on the product runs on the library's host loop (2.6 M nonzeros: 3 ms, against an upload per call), with a
+    device probe every 64 calls; NGT on the same arrays (nothing changes) stays on the device with one upload."""
+    out = _run_py(CHURN_SCRIPT % dict(root=ROOT), {"SPMV_HIP_DISPATCH": "auto"})
+    f = [l for l in out.splitlines() if l.startswith("CHURN")][0].split()[1:]
+    ok, calls, host_calls, uploads, us = f[0].split(":")
+    assert int(ok) == 1 and int(calls) == 150
+    assert int(host_calls) >= 140 and 3 <= int(uploads) <= 6, f  # 3 uploads until churning is seen, then probes
+    ok, calls, host_calls, uploads, us = f[1].split(":")
+    assert int(ok) == 1 and int(calls) == 150 and int(host_calls) == 0 and int(uploads) == 1, f
 
 
 def test_cli_drivers_on_the_hip_backend(pkg):
@@ -925,7 +1064,7 @@ def test_the_references_bfs_program_runs_on_the_library():
                            env=dict(os.environ, SPMV_HIP_STATS="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert float(r.stdout.strip().splitlines()[-1]) > 0.0
-    m = re.search(r"libhip-spmv: calls=(\d+) uploads=(\d+)", r.stderr)
+    m = re.search(r"libhip-spmv: calls=(\d+) \(host \d+\) uploads=(\d+)", r.stderr)
     assert m and int(m.group(1)) >= 16 and int(m.group(2)) == 1, r.stderr[-500:]
 
 
@@ -947,4 +1086,4 @@ def test_the_references_parboil_program_runs_on_the_library(pkg, tmp_path, datas
     b = np.fromfile(os.path.join(d, mtx + ".out"), np.uint8)
     assert a.size == b.size and np.array_equal(a[:4], b[:4])
     assert pkg.callers.pb_compare(b[4:].view(np.float32), a[4:].view(np.float32)) == 0
-    assert "libhip-spmv: calls=50 uploads=1" in r.stderr
+    assert "libhip-spmv: calls=50 (host 0) uploads=1" in r.stderr

@@ -58,9 +58,18 @@ def test_abi_harness_on_a_mock_device(tmp_path, san):
     runs += [({"SPMV_HIP_PARTS": "3", "SPMV_HIP_ZEROCOPY": "0"}, "mprotect"), ({"SPMV_HIP_PIN": "register"}, "mprotect"),
              ({"SPMV_HIP_PIN": "pageable"}, "mprotect"), ({"MOCK_NO_DEVPTR": "1"}, "mprotect")]
     for env, policy in runs:
+        # the mock device needs no GPU: point the presence probe at a node that exists; the scenarios are about the
+        # device-side logic, so the dispatch is forced there (its own scenario runs last, with auto)
         e = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1", TSAN_OPTIONS="halt_on_error=1",
-                 **env)
+                 SPMV_HIP_KFD_NODE="/dev/null", SPMV_HIP_DISPATCH="device", **env)
         r = subprocess.run([exe, policy], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=e, timeout=300)
         assert r.returncode == 0 and "all scenarios passed" in r.stdout, (env, r.stdout[-3000:])
         assert "runtime error" not in r.stdout and "ERROR: AddressSanitizer" not in r.stdout, (env, r.stdout[-3000:])
         assert "WARNING: ThreadSanitizer" not in r.stdout, (env, r.stdout[-3000:])
+    e = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1", SPMV_HIP_KFD_NODE="/dev/null",
+             SPMV_HIP_DISPATCH="auto")
+    r = subprocess.run([exe, "mprotect", "dispatch"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=e, timeout=300)
+    assert r.returncode == 0 and "ok host / device dispatch" in r.stdout, r.stdout[-3000:]
+    e["SPMV_HIP_KFD_NODE"] = "/nonexistent/kfd"  # no GPU: even a product the host loop would take aborts
+    r = subprocess.run([exe, "mprotect", "dispatch"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=e, timeout=300)
+    assert r.returncode != 0 and "no HIP device" in r.stdout, r.stdout[-3000:]

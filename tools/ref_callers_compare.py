@@ -5,6 +5,9 @@ oracle/Makefile) on the reference's CPU backend and on libhip-spmv.so, same inpu
   bfs      bfs/bfs.cc: 16 BFS from random sources on a graph read from stdin; prints its own elapsed seconds.
            Input: a seeded R-MAT graph written in the program's "rows cols nnz / x y" format.
   parboil  src/cpu/main.c: 50 products; prints its own Compute time.  Inputs: the bundled datasets.
+
+SPMV_HIP_DISPATCH is taken from the environment (default auto: small products run on the library's host loop and the
+HIP context is created only for a matrix that is worth it, csrc/spmv_harness.c dispatch_host).
 """
 import os
 import re
