@@ -96,6 +96,11 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param);
  * y_dev[0..rows) = A * x_dev, both DEVICE pointers on the matrix's device,
  * enqueued on `stream` (a hipStream_t; NULL = the library's own stream for
  * that device).  Asynchronous.  Replaces libspmv/gpu.c:270-282.
+ *
+ * ONE product in flight per matrix handle: the STRIPED plan's partial sums and the long-row kernels'
+ * partials are scratch buffers of the matrix, rewritten by every launch, so two products of the same
+ * handle on different streams (or from two host threads) must be ordered by the caller (the ABI path
+ * serialises its calls itself).  Different handles are independent.
  */
 int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *stream);
 /*

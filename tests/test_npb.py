@@ -2,6 +2,8 @@
 the verification table of NPB3.3.1/CG/cg.f:122-163 (epsilon 1e-10, cg.f:363-368), the class
 sizes measured on the reference binary (SURVEY.md 8(a) a3 / BASELINE.md section 2) and the
 literal restatement of makea/sparse in oracle/npb_makea_oracle.c."""
+import os
+
 import numpy as np
 import pytest
 
@@ -83,3 +85,18 @@ def test_row_blocks_are_slices_of_the_whole_matrix(pkg, parts):
         assert np.array_equal(b.colidx, w.colidx[s:e])
         assert np.array_equal(b.a.view(np.uint64), w.a[s:e].view(np.uint64))
         assert np.array_equal(b.rowstr, w.rowstr[b.row_begin:b.row_end + 1] - w.rowstr[b.row_begin] + 1)
+
+
+@pytest.mark.parametrize("cls", ["S", "W", "A"])
+def test_generated_matrices_match_the_committed_digests(pkg, cls):
+    """tests/golden/npb_digests.json: our own SHA-256 of rowstr / colidx / a (the values pass through libm's pow(),
+    cg.f:819, so a toolchain change could move bits).  SURVEY's FNV checksums of the Fortran arrays are not used: they
+    could not be reproduced with byte- or word-wise FNV-1a / FNV-1."""
+    import hashlib
+    import json
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "npb_digests.json")))["classes"][cls]
+    m = pkg.npb.NpbMatrix(cls)
+    assert (m.na, m.nnz) == (want["na"], want["nnz"])
+    for name in ("rowstr", "colidx", "a"):
+        got = hashlib.sha256(np.ascontiguousarray(getattr(m, name)).tobytes()).hexdigest()
+        assert got == want[name], (cls, name)
