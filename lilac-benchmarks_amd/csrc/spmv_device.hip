@@ -290,6 +290,7 @@ static void free_plans(spmv_hip_matrix *m)
     if (m->have_striped) {
         (void)hipFree((void *)m->ds.tptr);
         (void)hipFree((void *)m->ds.rrow);
+        (void)hipFree((void *)m->ds.wgd);
         (void)hipFree((void *)m->ds.col);
         (void)hipFree((void *)m->ds.val);
         if (m->ds.partial)
@@ -527,13 +528,17 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         spmv_set_error("matrix not representable in the STRIPED layout or not suited to it");
         return -2;
     }
-    const size_t ntp = (size_t)th.NG * (size_t)th.n_ranges * ((size_t)th.GM + 1);
+    const size_t ntp = (size_t)th.n_ranges * ((size_t)th.GM + 1);
     const size_t n_alloc = (size_t)th.n_packed + SPMV_TILE_PAD;
     const size_t pbytes = th.NG > 1 ? (size_t)th.NG * (size_t)m->rows * (size_t)m->elem + 64 : 0;
-    void *d_t = nullptr, *d_r = nullptr, *d_c = nullptr, *d_v = nullptr, *d_p = nullptr;
+    void *d_t = nullptr, *d_r = nullptr, *d_c = nullptr, *d_v = nullptr, *d_p = nullptr, *d_g = nullptr;
     hipError_t e = hipMalloc(&d_t, ntp * sizeof(int32_t));
     if (e == hipSuccess)
-        e = hipMalloc(&d_r, ((size_t)th.n_ranges + 1) * sizeof(int32_t));
+        e = hipMalloc(&d_r, ((size_t)th.n_ranges * 2 + 2) * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&d_g, ((size_t)th.n_wg * 4 + 4) * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMemcpy(d_g, th.wgd, (size_t)th.n_wg * 4 * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMalloc(&d_c, n_alloc * sizeof(uint16_t));
     if (e == hipSuccess)
@@ -543,7 +548,7 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     if (e == hipSuccess)
         e = hipMemcpy(d_t, th.tptr, ntp * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
-        e = hipMemcpy(d_r, th.rrow, ((size_t)th.n_ranges + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+        e = hipMemcpy(d_r, th.rrow, (size_t)th.n_ranges * 2 * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
@@ -551,11 +556,14 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     if (e != hipSuccess) {
         spmv_set_error("STRIPED upload failed: %s", hipGetErrorString(e));
         (void)hipFree(d_t), (void)hipFree(d_r), (void)hipFree(d_c), (void)hipFree(d_v), (void)hipFree(d_p);
+        (void)hipFree(d_g);
         spmv_striped_free(&th);
         return -1;
     }
     m->ds.tptr = (const int32_t *)d_t;
     m->ds.rrow = (const int32_t *)d_r;
+    m->ds.wgd = (const int32_t *)d_g;
+    m->ds.n_wg = th.n_wg;
     m->ds.col = (const uint16_t *)d_c;
     m->ds.val = d_v;
     m->ds.partial = d_p;
@@ -572,7 +580,7 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     m->ds.xbytes = so.xbytes;
     m->ds.rows = m->rows;
     m->ds.cols = m->cols;
-    m->device_bytes += ntp * 4 + ((size_t)th.n_ranges + 1) * 4 + n_alloc * (2 + (size_t)m->elem) + pbytes;
+    m->device_bytes += ntp * 4 + ((size_t)th.n_ranges * 2 + 2) * 4 + ((size_t)th.n_wg * 4 + 4) * 4 + n_alloc * (2 + (size_t)m->elem) + pbytes;
     m->have_striped = true;
     spmv_striped_free(&th);
     return 0;
@@ -833,7 +841,7 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     out->max_row_len = m->st.max_len;
     out->mean_row_len = m->st.mean_len;
     out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED     ? m->dt.B
-                    : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.NG * m->ds.NB
+                    : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.n_wg
                                                        : m->sp.nblk;
     out->n_long_rows = m->sp.n_long_rows;
     out->n_launches = n_launches(m);

@@ -449,11 +449,11 @@ void spmv_hip_release(void)
 }
 
 /*
- * Teardown.  Registered with atexit() from lazy_init, i.e. AFTER the HIP
- * runtime has initialised, so it runs BEFORE the runtime's own exit handlers
- * (handlers run in reverse order of registration) and, being registered from
- * inside this DSO, also when the library is dlclose()d (pagerank does that,
- * /root/reference/pagerank/main.cpp:25-30).
+ * Teardown.  Registered with atexit() from lazy_init (a process that only ever used the host loop still
+ * prints its statistics) and AGAIN from device_init, i.e. after the HIP runtime has initialised, so that it
+ * runs BEFORE the runtime's own exit handlers (handlers run in reverse order of registration) and, being
+ * registered from inside this DSO, also when the library is dlclose()d (pagerank does that,
+ * /root/reference/pagerank/main.cpp:25-30).  Idempotent.
  */
 static void lib_fini(void)
 {
@@ -573,6 +573,9 @@ static void device_init(void)
     if (!probe)
         die("device initialisation failed: %s", spmv_hip_last_error());
     spmv_hip_free(0, probe);
+    /* again, now that the HIP runtime has registered its own exit handlers: handlers run in reverse order of
+     * registration, so this one frees the device copies BEFORE the runtime goes away (lib_fini runs once) */
+    atexit(lib_fini);
     G.dev_inited = 1;
     G.st.t_init = spmv_now() - t0;
 }

@@ -139,15 +139,17 @@ typedef struct spmv_striped_opts {
 } spmv_striped_opts;
 typedef struct spmv_striped_host {
     int elem, W, S, WPB, EPL;
-    int NB, NG, GM;  /* row blocks, stripe groups, most stripes per group                          */
-    int n_ranges;    /* NB * WPB wave ranges                                                         */
+    int NB, NG, GM;  /* most row blocks of a group, stripe groups, most stripes per group             */
+    int n_wg;        /* workgroups = all groups' row blocks                                           */
+    int n_ranges;    /* n_wg * WPB wave ranges                                                        */
     int cap;         /* elements of the kernel's LDS buffer; cap - 1 = the zero column               */
     int skewed;      /* one tile dwarfs the others (a dense row): the automatic choice declines      */
     int64_t n_packed, n_dummies, max_tile;
     void *val;
     uint16_t *col;
-    int32_t *tptr; /* [NG * n_ranges * (GM + 1)] tile starts, see spmv_striped.c */
-    int32_t *rrow; /* [n_ranges + 1] first row of each wave range               */
+    int32_t *tptr; /* [n_ranges * (GM + 1)] tile starts, see spmv_striped.c        */
+    int32_t *rrow; /* [n_ranges * 2] first and end row of each wave range          */
+    int32_t *wgd;  /* [n_wg * 4] first stripe, end stripe, group, row block of it  */
 } spmv_striped_host;
 
 void spmv_striped_default_opts(spmv_striped_opts *o);
@@ -188,10 +190,11 @@ int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream);
 typedef struct spmv_dev_striped {
     const int32_t *tptr;
     const int32_t *rrow;
+    const int32_t *wgd;
     const uint16_t *col;
     const void *val;
     void *partial;          /* T[NG * rows], NULL when NG == 1 */
-    int elem, W, S, WPB, NB, NG, GM, EPL, n_ranges, wave_rows, rows, cols;
+    int elem, W, S, WPB, NB, NG, GM, EPL, n_wg, n_ranges, wave_rows, rows, cols;
     int xbytes; /* LDS stripe capacity the layout was built for */
 } spmv_dev_striped;
 struct spmv_hip_matrix;

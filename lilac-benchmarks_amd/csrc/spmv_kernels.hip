@@ -565,7 +565,7 @@ done:
 
 /* ================================ k_striped ===================================== */
 /*
- * STRIPED plan (layout: spmv_striped.c).  Workgroup = (stripe group g, row block rb).  It walks the
+ * STRIPED plan (layout: spmv_striped.c).  Workgroup = (stripe group g, row block rb of that group).  It walks the
  * stripes of its group: copy the stripe of x into LDS (one staging, two LDS-only barriers), then
  * every wave is on its own until the stripe ends, streaming the tile of ITS rows -- packed (value,
  * flagged 16-bit column) entries -- through a ring of register sets reloaded in place; the wave's
@@ -635,10 +635,10 @@ template <typename T, int NACC> __device__ __forceinline__ void acc_add(T (&acc)
 
 template <typename T, int WPB, int R, int XT_BYTES, int EPL, int NACC>
 __global__ void __launch_bounds__(WPB * 64, 4)
-k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const unsigned short *__restrict__ pcol,
-          const T *__restrict__ pval, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ partial,
-          const T *__restrict__ dotv, T *__restrict__ dot_part, int rows,
-          int cols, int S, int NB, int NG, int GM, int wcols, int nwg, int per_xcd, int abl)
+k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int *__restrict__ wgd,
+          const unsigned short *__restrict__ pcol, const T *__restrict__ pval, const T *__restrict__ x,
+          T *__restrict__ y, T *__restrict__ partial, const T *__restrict__ dotv, T *__restrict__ dot_part, int rows,
+          int cols, int NG, int GM, int wcols, int nwg, int per_xcd, int abl)
 {
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E;
@@ -657,12 +657,12 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const unsi
     if (q >= nwg)
         return; /* the whole workgroup */
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int g = q / NB, rb = q - g * NB;
-    const int u = rb * WPB + w; /* wave range */
-    const int row0 = __builtin_amdgcn_readfirstlane(rrow[u]);
-    const unsigned int nr = (unsigned int)(__builtin_amdgcn_readfirstlane(rrow[u + 1]) - row0);
-    const int s0 = (int)((long long)g * S / NG), s1 = (int)((long long)(g + 1) * S / NG);
-    const int *__restrict__ tp = tptr + ((size_t)g * (size_t)(NB * WPB) + (size_t)u) * (size_t)(GM + 1);
+    const int s0 = __builtin_amdgcn_readfirstlane(wgd[4 * q]), s1 = __builtin_amdgcn_readfirstlane(wgd[4 * q + 1]);
+    const int g = __builtin_amdgcn_readfirstlane(wgd[4 * q + 2]);
+    const int u = q * WPB + w; /* wave range */
+    const int row0 = __builtin_amdgcn_readfirstlane(rrow[2 * u]);
+    const unsigned int nr = (unsigned int)(__builtin_amdgcn_readfirstlane(rrow[2 * u + 1]) - row0);
+    const int *__restrict__ tp = tptr + (size_t)u * (size_t)(GM + 1);
 
     T acc[NACC];
 #pragma unroll
@@ -1204,14 +1204,14 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
     if (t->WPB != SPMV_STRIPE_WPB || t->xbytes != SPMV_STRIPE_XBYTES || t->EPL != SPMV_STRIPE_EPL ||
         t->wave_rows > SPMV_STRIPE_WAVE_ROWS || (t->NG > 1 && !t->partial))
         return (int)hipErrorInvalidValue;
-    const int nwg = t->NB * t->NG;
+    const int nwg = t->n_wg;
     const int per = g_tune_xcd ? (nwg + 7) / 8 : 0; /* workgroups of one stripe group share an XCD's L2 for x */
     const int grid = per ? per * 8 : nwg;
 #define SPMV_LS2(T, R)                                                                                          \
     hipLaunchKernelGGL((k_striped<T, SPMV_STRIPE_WPB, R, SPMV_STRIPE_XBYTES, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC>), \
-                       dim3(grid), dim3(SPMV_STRIPE_WPB * 64), 0, st, t->tptr, t->rrow, t->col, (const T *)t->val, \
-                       (const T *)x, (T *)y, (T *)t->partial, (const T *)dotv, (T *)dot_part, t->rows,             \
-                       t->cols, t->S, t->NB, t->NG, t->GM, t->W, nwg, per, g_tune_abl)
+                       dim3(grid), dim3(SPMV_STRIPE_WPB * 64), 0, st, t->tptr, t->rrow, t->wgd, t->col,           \
+                       (const T *)t->val, (const T *)x, (T *)y, (T *)t->partial, (const T *)dotv, (T *)dot_part,  \
+                       t->rows, t->cols, t->NG, t->GM, t->W, nwg, per, g_tune_abl)
 #define SPMV_LS2R(T)                                                                                            \
     do {                                                                                                        \
         if (g_tune_tile_k == 4)                                                                                 \

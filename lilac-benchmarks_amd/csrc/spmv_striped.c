@@ -3,10 +3,11 @@
  * by k_striped (plain C, no GPU needed).
  *
  * STRIPED is the 2-D decomposition of y = A*x.  The columns are cut into S stripes of W columns
- * (W * sizeof(T) <= 128 KiB of x: one stripe fits the LDS of a CU) and the rows into NB row blocks
- * of WPB wave ranges each (a wave range = at most `wave_rows` consecutive rows, all ranges of about
- * equal nonzero counts, the SAME cuts for every stripe).  The stripes are dealt to NG groups of
- * consecutive stripes, and a workgroup = (stripe group g, row block rb).  It walks the stripes of its
+ * (W * sizeof(T) <= 128 KiB of x: one stripe fits the LDS of a CU), and the stripes are dealt to NG
+ * groups of consecutive stripes.  Every group cuts the rows into its own row blocks of WPB wave ranges
+ * each (a wave range = at most `wave_rows` consecutive rows; all ranges of a group hold the same number
+ * of entries OF THAT GROUP's stripes, and a group gets row blocks in proportion to its entries), and a
+ * workgroup = (stripe group g, row block rb of g).  It walks the stripes of its
  * group one after the other: copy the stripe of x into LDS, then each of its WPB waves streams the
  * entries of ITS rows that fall into that stripe -- the per-nonzero gather of x is an LDS access --
  * and adds each row's sum for the stripe into a per-row accumulator that lives in the wave's
@@ -22,15 +23,16 @@
  *
  * Layout (offsets in entries):
  *
- *   tile (g, rb, w, si)   the entries of wave range (rb, w) in stripe s = s0(g) + si, row after row,
- *                         each row's entries in their original CSR order; a whole number of
- *                         sub-windows of 64*EPL entries (pads: value 0, the zero column, no flag);
- *                         a wave's tiles follow each other in memory (one linear stream per wave per
- *                         workgroup), waves of a workgroup and workgroups (g-major) follow each other;
- *   tptr[]                int32 [(NG*NB*WPB) * (GM + 1)]: tile starts of wave (g, rb, w), GM =
+ *   tile (q, w, si)       workgroup q = (g, rb), wave w, stripe s = s0(g) + si: the entries of the wave's
+ *                         rows in that stripe, row after row, each row's entries in their original
+ *                         CSR order; a whole number of sub-windows of 64*EPL entries (pads: value 0,
+ *                         the zero column, no flag); a wave's tiles follow each other in memory (one
+ *                         linear stream per wave), waves and workgroups (g-major) follow each other;
+ *   wgd[]                 int32 [n_wg * 4]: first stripe, end stripe and group of workgroup q;
+ *   tptr[]                int32 [(n_wg*WPB) * (GM + 1)]: tile starts of wave u = q*WPB + w, GM =
  *                         ceil(S / NG) stripes per group at most, entry GM (and those past the
  *                         group's last stripe) = end of the wave's stream;
- *   rrow[]                int32 [NB*WPB + 1]: first row of every wave range;
+ *   rrow[]                int32 [n_wg*WPB * 2]: first and end row of wave u;
  *   val[]                 T, packed; inside each sub-window lane-interleaved in 16-byte units: entry
  *                         e = l*EPL + i sits at (i/G)*(64*G) + l*G + i%G, G = 16/sizeof(T), so that
  *                         lane l, which owns entries l*EPL.., reads them with dense 16-byte loads;
@@ -58,6 +60,7 @@ void spmv_striped_free(spmv_striped_host *t)
     free(t->col);
     free(t->tptr);
     free(t->rrow);
+    free(t->wgd);
     memset(t, 0, sizeof *t);
 }
 
@@ -70,6 +73,7 @@ void spmv_striped_default_opts(spmv_striped_opts *o)
     o->groups = 0;
 }
 
+/* stripes and stripe groups; the row blocks per group are decided by the builder, from the entries */
 void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped_opts *o, spmv_striped_host *t)
 {
     memset(t, 0, sizeof *t);
@@ -83,10 +87,26 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped
     /* the top 16 bytes of the buffer are not x: its last element is kept at 0 and is what fillers and pads
      * multiply with */
     wmax -= 16 / elem_size;
-    /* fewest stripes that fit LDS, all of the same width (with full-width stripes and a remainder, the last
-     * stripe of NPB class C held 1.7 % of the nonzeros but a tenth of the workgroups) */
-    int s_min = cols > 0 ? (cols + wmax - 1) / wmax : 1;
     const int unit = 16 / elem_size; /* stripes start on 16-byte boundaries of x */
+    int s_min = cols > 0 ? (cols + wmax - 1) / wmax : 1;
+    /*
+     * Stripe groups.  A wave holds at most wave_rows row accumulators, which sets the least number of row
+     * blocks; within that, as many stripe groups as keep the workgroups within the target (every workgroup
+     * resident at once: one 160-KiB workgroup per CU), because fewer stripes per workgroup mean fewer
+     * re-stagings of x and longer uninterrupted streams, and the partial sums that more groups cost are
+     * few: class C 10 groups x 25 row blocks (12 MB of partials beside a 373 MB stream), a class D row
+     * block of 187 500 rows 21 groups of 4-5 stripes, all of class D 2 groups x 128 row blocks.
+     */
+    const int target = o->target_wgs < 1 ? 1 : o->target_wgs;
+    const int64_t per_block = (int64_t)o->wpb * o->wave_rows;
+    const int nb_min = rows > 0 ? (int)((rows + per_block - 1) / per_block) : 1;
+    int ng = o->groups > 0 ? o->groups : target / nb_min;
+    if (ng < 1)
+        ng = 1;
+    if (ng > s_min)
+        ng = s_min;
+    /* all stripes of the same width (with full-width stripes and a remainder, the last stripe of NPB class C
+     * held 1.7 % of the nonzeros but a tenth of the workgroups) */
     int w = cols > 0 ? ((cols + s_min - 1) / s_min + unit - 1) / unit * unit : wmax;
     if (w > wmax)
         w = wmax;
@@ -94,32 +114,10 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped
         w = unit;
     t->W = w;
     t->S = cols > 0 ? (cols + w - 1) / w : 1;
-    /*
-     * Row blocks and stripe groups.  A wave holds at most wave_rows row accumulators, which sets the
-     * least number of row blocks; within that, as many stripe groups as keep NB * NG within the target
-     * (every workgroup resident at once: one 160-KiB workgroup per CU), because fewer stripes per
-     * workgroup mean fewer re-stagings of x and longer uninterrupted streams, and the partial sums
-     * that more groups cost are few: class C 10 groups x 25 row blocks (12 MB of partials beside a
-     * 373 MB stream), a class D row block of 187 500 rows 21 x 12 (4-5 stripes per group), all of
-     * class D 2 x 128.
-     */
-    const int target = o->target_wgs < 1 ? 1 : o->target_wgs;
-    const int64_t per_block = (int64_t)o->wpb * o->wave_rows;
-    int nb_min = rows > 0 ? (int)((rows + per_block - 1) / per_block) : 1;
-    int ng = o->groups > 0 ? o->groups : target / nb_min;
-    if (ng < 1)
-        ng = 1;
     if (ng > t->S)
         ng = t->S;
-    int nb = target / ng;
-    if (nb < nb_min)
-        nb = nb_min;
-    while (nb > nb_min && (int64_t)nb * o->wpb > (int64_t)rows) /* no point in more waves than rows */
-        --nb;
-    t->NB = nb;
     t->NG = ng;
     t->GM = (t->S + ng - 1) / ng;
-    t->n_ranges = nb * o->wpb;
 }
 
 /* exact c / W for 0 <= c < 2^31 without a hardware divide per nonzero */
@@ -147,57 +145,130 @@ static inline uint32_t fastdiv_do(fastdiv d, uint32_t c)
 typedef struct build_ctx {
     const void *a;
     const int *rowstr, *colidx;
-    int r0, rows, cols, elem, S, W, NB, NG, GM, WPB, EPL, G, cap;
+    int r0, rows, cols, elem, S, W, NG, GM, WPB, EPL, G, cap;
     int64_t SUB;
     fastdiv div;
-    int64_t *tsize;   /* [n_ranges][S] padded tile sizes */
-    int64_t *rfill;   /* [n_ranges] fillers */
-    int *sg, *ssi;    /* [S] group of a stripe and its index inside the group */
+    int *sg;          /* [S] group of a stripe                                                  */
+    int *gs0;         /* [NG + 1] first stripe of a group                                       */
+    uint32_t *wgt;    /* [NG][rows] entries (fillers included) of a row in a group's stripes    */
+    int64_t *tsize;   /* [n_ranges][GM] padded tile sizes                                       */
+    int64_t *rfill;   /* [n_ranges] fillers                                                     */
     spmv_striped_host *t;
-    volatile int bad; /* 1: a column outside [1, cols]; 2: out of memory */
+    int unsorted;          /* some row's columns decrease: a group's entries are not one run of the row */
+    int bad;               /* 1: a column outside [1, cols]; 2: out of memory (set by any thread, read after the pass) */
 } build_ctx;
 
-/* pass 1, over wave ranges: entries (fillers included) per (range, stripe) */
+/* pass 1, over rows: entries + fillers of every row in every stripe group; are the rows sorted? */
+static void pass_weigh(int64_t lo, int64_t hi, void *vc)
+{
+    build_ctx *c = (build_ctx *)vc;
+    const int S = c->S, NG = c->NG;
+    int64_t *stamp = (int64_t *)malloc((size_t)S * sizeof(int64_t));
+    uint32_t *cnt = (uint32_t *)malloc((size_t)NG * 2 * sizeof(uint32_t));
+    if (!stamp || !cnt) {
+        __atomic_store_n(&c->bad, 2, __ATOMIC_RELAXED);
+        free(stamp), free(cnt);
+        return;
+    }
+    uint32_t *touched = cnt + NG;
+    for (int s = 0; s < S; ++s)
+        stamp[s] = -1;
+    int unsorted = 0;
+    for (int64_t r = lo; r < hi; ++r) {
+        memset(cnt, 0, (size_t)NG * 2 * sizeof(uint32_t));
+        int prev = 0;
+        for (int j = c->rowstr[c->r0 + r] - 1; j < c->rowstr[c->r0 + r + 1] - 1; ++j) {
+            const int col = c->colidx[j] - 1;
+            if (col < 0 || col >= c->cols) {
+                __atomic_store_n(&c->bad, 1, __ATOMIC_RELAXED);
+                free(stamp), free(cnt);
+                return;
+            }
+            unsorted |= col < prev;
+            prev = col;
+            const uint32_t s = fastdiv_do(c->div, (uint32_t)col);
+            const int g = c->sg[s];
+            cnt[g]++;
+            if (stamp[s] != r)
+                stamp[s] = r, touched[g]++;
+        }
+        for (int g = 0; g < NG; ++g)
+            c->wgt[(size_t)g * c->rows + r] = cnt[g] + (uint32_t)(c->gs0[g + 1] - c->gs0[g]) - touched[g];
+    }
+    if (unsorted) /* several threads may find this out: the same value from all of them */
+        __atomic_store_n(&c->unsorted, 1, __ATOMIC_RELAXED);
+    free(stamp), free(cnt);
+}
+
+/* the entries of row r (local) that fall into stripes [s0, s1): a run [*jb, *je) of the row when its columns are
+ * sorted; otherwise the whole row, to be filtered */
+static inline void group_run(const build_ctx *c, int r, int s0, int s1, int *jb, int *je)
+{
+    int b = c->rowstr[c->r0 + r] - 1, e = c->rowstr[c->r0 + r + 1] - 1;
+    if (!c->unsorted) {
+        const int64_t clo = (int64_t)s0 * c->W + 1, chi = (int64_t)s1 * c->W + 1; /* 1-based bounds */
+        int lo = b, hi = e;
+        while (lo < hi) { /* first entry with colidx >= clo */
+            const int mid = lo + (hi - lo) / 2;
+            if (c->colidx[mid] < clo)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        b = lo;
+        hi = e;
+        while (lo < hi) { /* first entry with colidx >= chi */
+            const int mid = lo + (hi - lo) / 2;
+            if (c->colidx[mid] < chi)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        e = lo;
+    }
+    *jb = b, *je = e;
+}
+
+/* pass 2, over wave ranges: entries (fillers included) per (range, stripe of its group) */
 static void pass_count(int64_t lo, int64_t hi, void *vc)
 {
     build_ctx *c = (build_ctx *)vc;
-    const int S = c->S;
-    int32_t *stamp = (int32_t *)malloc((size_t)S * sizeof(int32_t));
-    if (!stamp) {
-        c->bad = 2;
+    const int GM = c->GM;
+    int64_t *seen = (int64_t *)malloc((size_t)GM * sizeof(int64_t));
+    if (!seen) {
+        __atomic_store_n(&c->bad, 2, __ATOMIC_RELAXED);
         return;
     }
     for (int64_t u = lo; u < hi; ++u) {
-        int64_t *cnt = c->tsize + (size_t)u * S;
-        memset(cnt, 0, (size_t)S * sizeof(int64_t));
-        for (int s = 0; s < S; ++s)
-            stamp[s] = -1;
+        const int32_t *d = c->t->wgd + (size_t)(u / c->WPB) * 4;
+        const int s0 = d[0], s1 = d[1], ns = s1 - s0;
+        int64_t *cnt = c->tsize + (size_t)u * GM;
+        memset(cnt, 0, (size_t)GM * sizeof(int64_t));
+        for (int k = 0; k < GM; ++k)
+            seen[k] = -1;
         int64_t fillers = 0;
-        for (int r = c->t->rrow[u]; r < c->t->rrow[u + 1]; ++r) {
-            int distinct = 0;
-            for (int j = c->rowstr[c->r0 + r] - 1; j < c->rowstr[c->r0 + r + 1] - 1; ++j) {
-                const int col = c->colidx[j] - 1;
-                if (col < 0 || col >= c->cols) {
-                    c->bad = 1;
-                    free(stamp);
-                    return;
-                }
-                const uint32_t s = fastdiv_do(c->div, (uint32_t)col);
-                cnt[s]++;
-                if (stamp[s] != r)
-                    stamp[s] = r, ++distinct;
+        for (int r = c->t->rrow[2 * u]; r < c->t->rrow[2 * u + 1]; ++r) {
+            int jb, je, distinct = 0;
+            group_run(c, r, s0, s1, &jb, &je);
+            for (int j = jb; j < je; ++j) {
+                const int s = (int)fastdiv_do(c->div, (uint32_t)(c->colidx[j] - 1));
+                if (s < s0 || s >= s1)
+                    continue; /* unsorted rows: not this group's entry */
+                cnt[s - s0]++;
+                if (seen[s - s0] != r)
+                    seen[s - s0] = r, ++distinct;
             }
-            if (distinct < S) {
-                for (int s = 0; s < S; ++s)
-                    cnt[s] += stamp[s] != r;
-                fillers += S - distinct;
+            if (distinct < ns) {
+                for (int k = 0; k < ns; ++k)
+                    cnt[k] += seen[k] != r;
+                fillers += ns - distinct;
             }
         }
         c->rfill[u] = fillers;
-        for (int s = 0; s < S; ++s)
-            cnt[s] = (cnt[s] + c->SUB - 1) / c->SUB * c->SUB;
+        for (int k = 0; k < GM; ++k)
+            cnt[k] = (cnt[k] + c->SUB - 1) / c->SUB * c->SUB;
     }
-    free(stamp);
+    free(seen);
 }
 
 static inline int64_t val_slot(const build_ctx *c, int64_t p)
@@ -209,80 +280,81 @@ static inline int64_t val_slot(const build_ctx *c, int64_t p)
     return blk + (i / c->G) * (64 * c->G) + l * c->G + (i % c->G);
 }
 
-/* pass 2, over wave ranges: scatter in CSR order; a range's tiles are touched by its own thread only */
+/* pass 3, over wave ranges: scatter in CSR order; a range's tiles are touched by its own thread only */
 static void pass_scatter(int64_t lo, int64_t hi, void *vc)
 {
     build_ctx *c = (build_ctx *)vc;
-    const int S = c->S, W = c->W;
-    int32_t *stamp = (int32_t *)malloc((size_t)S * sizeof(int32_t));
-    int64_t *pos = (int64_t *)malloc((size_t)S * sizeof(int64_t));
-    int64_t *last = (int64_t *)malloc((size_t)S * sizeof(int64_t));
-    if (!stamp || !pos || !last) {
-        c->bad = 2;
-        free(stamp), free(pos), free(last);
+    const int GM = c->GM, W = c->W;
+    int64_t *seen = (int64_t *)malloc((size_t)GM * 3 * sizeof(int64_t));
+    if (!seen) {
+        __atomic_store_n(&c->bad, 2, __ATOMIC_RELAXED);
         return;
     }
+    int64_t *pos = seen + GM, *last = seen + 2 * GM;
     uint16_t *tcol = c->t->col;
     const uint16_t zero_col = (uint16_t)(c->cap - 1);
-    const int nr = c->t->n_ranges;
     for (int64_t u = lo; u < hi; ++u) {
-        for (int s = 0; s < S; ++s) {
-            pos[s] = c->t->tptr[((size_t)c->sg[s] * nr + (size_t)u) * ((size_t)c->GM + 1) + c->ssi[s]];
-            stamp[s] = -1;
-        }
-        for (int r = c->t->rrow[u]; r < c->t->rrow[u + 1]; ++r) {
-            int distinct = 0;
-            for (int j = c->rowstr[c->r0 + r] - 1; j < c->rowstr[c->r0 + r + 1] - 1; ++j) {
+        const int32_t *d = c->t->wgd + (size_t)(u / c->WPB) * 4;
+        const int s0 = d[0], s1 = d[1], ns = s1 - s0;
+        const int32_t *tp = c->t->tptr + (size_t)u * ((size_t)GM + 1);
+        for (int k = 0; k < ns; ++k)
+            pos[k] = tp[k], seen[k] = -1;
+        for (int r = c->t->rrow[2 * u]; r < c->t->rrow[2 * u + 1]; ++r) {
+            int jb, je, distinct = 0;
+            group_run(c, r, s0, s1, &jb, &je);
+            for (int j = jb; j < je; ++j) {
                 const int col = c->colidx[j] - 1;
-                const uint32_t s = fastdiv_do(c->div, (uint32_t)col);
-                const int64_t p = pos[s]++;
-                tcol[p] = (uint16_t)(col - (int)s * W);
+                const int s = (int)fastdiv_do(c->div, (uint32_t)col);
+                if (s < s0 || s >= s1)
+                    continue;
+                const int k = s - s0;
+                const int64_t p = pos[k]++;
+                tcol[p] = (uint16_t)(col - s * W);
                 const int64_t v = val_slot(c, p);
                 if (c->elem == 8)
                     ((double *)c->t->val)[v] = ((const double *)c->a)[j];
                 else
                     ((float *)c->t->val)[v] = ((const float *)c->a)[j];
-                last[s] = p;
-                if (stamp[s] != r)
-                    stamp[s] = r, ++distinct;
+                last[k] = p;
+                if (seen[k] != r)
+                    seen[k] = r, ++distinct;
             }
-            if (distinct == S) {
-                for (int s = 0; s < S; ++s)
-                    tcol[last[s]] |= 0x8000u; /* last entry of this row in this stripe */
+            if (distinct == ns) {
+                for (int k = 0; k < ns; ++k)
+                    tcol[last[k]] |= 0x8000u; /* last entry of this row in this stripe */
             } else {
-                for (int s = 0; s < S; ++s)
-                    if (stamp[s] == r)
-                        tcol[last[s]] |= 0x8000u;
+                for (int k = 0; k < ns; ++k)
+                    if (seen[k] == r)
+                        tcol[last[k]] |= 0x8000u;
                     else /* the filler of an empty segment: flag only, value 0 (calloc), times the zero column */
-                        tcol[pos[s]++] = (uint16_t)(0x8000u | zero_col);
+                        tcol[pos[k]++] = (uint16_t)(0x8000u | zero_col);
             }
         }
         /* the rest of every tile is padding: value 0 (calloc) times the zero column, no flag */
-        for (int s = 0; s < S; ++s) {
-            const int64_t end = c->t->tptr[((size_t)c->sg[s] * nr + (size_t)u) * ((size_t)c->GM + 1) + c->ssi[s] + 1];
-            for (int64_t p = pos[s]; p < end; ++p)
+        for (int k = 0; k < ns; ++k)
+            for (int64_t p = pos[k]; p < tp[k + 1]; ++p)
                 tcol[p] = zero_col;
-        }
     }
-    free(stamp), free(pos), free(last);
+    free(seen);
 }
 
 /*
- * The wave ranges: NB*WPB runs of consecutive rows of about equal weight (nonzeros + 1), none longer
- * than wave_rows rows, every one non-empty while rows last.
+ * The wave ranges of one group: n runs of consecutive rows of about equal weight (the group's entries per row),
+ * none longer than wave_rows rows, every one non-empty while rows last.  rr[2 i], rr[2 i + 1] = first / end row.
  */
-static void cut_rows(const int *rowstr, int r0, int rows, int n_ranges, int wave_rows, int32_t *rrow)
+static void cut_rows(const uint32_t *wgt, int rows, int n, int wave_rows, int32_t *rr)
 {
-    int64_t remaining = (int64_t)rowstr[r0 + rows] - rowstr[r0] + rows;
+    int64_t remaining = 0;
+    for (int r = 0; r < rows; ++r)
+        remaining += wgt[r];
     int r = 0;
-    for (int i = 0; i < n_ranges; ++i) {
-        rrow[i] = r;
-        const int left = n_ranges - i;
+    for (int i = 0; i < n; ++i) {
+        const int first = r, left = n - i;
         const int64_t target = (remaining + left - 1) / left;
         int64_t acc = 0;
         while (r < rows) {
-            const int64_t w = (int64_t)rowstr[r0 + r + 1] - rowstr[r0 + r] + 1;
-            const int taken = r - rrow[i];
+            const int64_t w = wgt[r];
+            const int taken = r - first;
             /* the ranges after this one hold (left - 1) * wave_rows rows at most */
             const int must = (int64_t)(rows - r) > (int64_t)(left - 1) * wave_rows;
             if (!must) {
@@ -297,8 +369,54 @@ static void cut_rows(const int *rowstr, int r0, int rows, int n_ranges, int wave
             ++r;
         }
         remaining -= acc;
+        rr[2 * i] = first, rr[2 * i + 1] = r;
     }
-    rrow[n_ranges] = rows;
+}
+
+/*
+ * How many stripe groups?  S stripes rarely divide into the groups: groups of ceil(S/ng) and of floor(S/ng) stripes
+ * get row blocks in proportion to their stripes, never fewer than nb_min (the accumulators), and all blocks together
+ * must not outnumber the target (a workgroup that does not fit waits for a whole round).  A workgroup's time is
+ * modelled as stripes x (its waves' tile, rounded up to whole sub-windows, + RESTAGE entries for the change of
+ * stripe: two barriers and 128 KB of x cost a wave about what 500 entries do); of the group counts from `ng_max`
+ * downwards the one with the cheapest most expensive workgroup wins, the larger count on a tie.  Class C: 10 groups
+ * of 1 stripe (25-26 row blocks each); a class D row block of 187 500 rows: 20 groups (21 would need 261 workgroups);
+ * all of class D: 2 groups of 46 stripes.
+ */
+#define STRIPE_RESTAGE_ENTRIES 512
+static int choose_groups(int S, int ng_max, int nb_min, int target, int wpb, int64_t nnz, int64_t sub)
+{
+    int best = ng_max;
+    double best_cost = 1e300;
+    const double per_stripe = (double)nnz / (double)S;
+    for (int cand = ng_max; cand >= 1 && cand >= ng_max - 24; --cand) {
+        const int big = (S + cand - 1) / cand, small = S / cand; /* stripes per group */
+        const int n_big = S - small * cand, n_small = cand - n_big;
+        int nb_big = (int)((int64_t)target * big / S), nb_small = (int)((int64_t)target * small / S);
+        nb_big = nb_big < nb_min ? nb_min : nb_big;
+        nb_small = nb_small < nb_min ? nb_min : nb_small;
+        int left = target - (n_big * nb_big + n_small * nb_small);
+        if (left < 0 && cand > 1)
+            continue;
+        /* what is left of the target: a block more for every group of a kind, the larger groups first */
+        if (n_big > 0 && left >= n_big)
+            ++nb_big, left -= n_big;
+        if (n_small > 0 && left >= n_small)
+            ++nb_small, left -= n_small;
+        double cost = 0.0;
+        for (int kind = 0; kind < 2; ++kind) {
+            const int n = kind ? n_small : n_big, st = kind ? small : big, nb = kind ? nb_small : nb_big;
+            if (n == 0)
+                continue;
+            const double tile = per_stripe / ((double)nb * wpb);
+            const double padded = (double)(((int64_t)tile + sub - 1) / sub * sub);
+            const double c = st * (padded + STRIPE_RESTAGE_ENTRIES);
+            cost = c > cost ? c : cost;
+        }
+        if (cost < best_cost * (1.0 - 1e-9))
+            best_cost = cost, best = cand;
+    }
+    return best;
 }
 
 /*
@@ -316,65 +434,151 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
         opts = &dflt;
     }
     spmv_striped_geometry(rows, cols, elem_size, opts, t);
-    const int S = t->S;
+    if (opts->groups <= 0 && t->NG > 1 && rows > 0) {
+        const int64_t per_block = (int64_t)opts->wpb * opts->wave_rows;
+        t->NG = choose_groups(t->S, t->NG, (int)((rows + per_block - 1) / per_block), opts->target_wgs < 1 ? 1 : opts->target_wgs,
+                              opts->wpb, (int64_t)rowstr[r1] - rowstr[r0], 64 * (int64_t)t->EPL);
+        t->GM = (t->S + t->NG - 1) / t->NG;
+    }
+    const int S = t->S, NG = t->NG, GM = t->GM, WPB = t->WPB;
     if (rows <= 0 || opts->wave_rows < 64 || opts->wave_rows % 64 || S > 32768 /* fastdiv_do */ ||
-        (int64_t)t->n_ranges * S > ((int64_t)1 << 26))
+        (int64_t)NG * rows > ((int64_t)1 << 28))
         return -2;
     const int64_t nnz = (int64_t)rowstr[r1] - rowstr[r0];
-    const int nr = t->n_ranges;
 
     build_ctx c;
     memset(&c, 0, sizeof c);
     c.a = a, c.rowstr = rowstr, c.colidx = colidx;
     c.r0 = r0, c.rows = rows, c.cols = cols, c.elem = elem_size;
-    c.S = S, c.W = t->W, c.NB = t->NB, c.NG = t->NG, c.GM = t->GM, c.WPB = t->WPB, c.EPL = t->EPL;
+    c.S = S, c.W = t->W, c.NG = NG, c.GM = GM, c.WPB = WPB, c.EPL = t->EPL;
     c.G = 16 / elem_size; /* values per 16-byte unit */
     c.cap = t->cap;
     c.SUB = 64 * (int64_t)t->EPL; /* entries per sub-window */
     c.div = fastdiv_make(t->W);
     c.t = t;
     int rc = -1;
-    c.tsize = (int64_t *)malloc((size_t)nr * S * sizeof(int64_t));
-    c.rfill = (int64_t *)calloc((size_t)nr, sizeof(int64_t));
+    int *gnb = NULL;
+    int64_t *gent = NULL;
     c.sg = (int *)malloc((size_t)S * sizeof(int));
-    c.ssi = (int *)malloc((size_t)S * sizeof(int));
-    t->rrow = (int32_t *)calloc((size_t)nr + 1, sizeof(int32_t));
-    const size_t ntp = (size_t)t->NG * nr * ((size_t)t->GM + 1);
-    t->tptr = (int32_t *)calloc(ntp, sizeof(int32_t));
-    if (!c.tsize || !c.rfill || !c.sg || !c.ssi || !t->rrow || !t->tptr)
+    c.gs0 = (int *)malloc(((size_t)NG + 1) * sizeof(int));
+    c.wgt = (uint32_t *)malloc((size_t)NG * rows * sizeof(uint32_t));
+    gnb = (int *)malloc((size_t)NG * sizeof(int));
+    gent = (int64_t *)calloc((size_t)NG, sizeof(int64_t));
+    if (!c.sg || !c.gs0 || !c.wgt || !gnb || !gent)
         goto out;
-    for (int g = 0; g < t->NG; ++g)
-        for (int s = (int)((int64_t)g * S / t->NG); s < (int)((int64_t)(g + 1) * S / t->NG); ++s)
-            c.sg[s] = g, c.ssi[s] = s - (int)((int64_t)g * S / t->NG);
+    for (int g = 0; g <= NG; ++g)
+        c.gs0[g] = (int)((int64_t)g * S / NG);
+    for (int g = 0; g < NG; ++g)
+        for (int s = c.gs0[g]; s < c.gs0[g + 1]; ++s)
+            c.sg[s] = g;
 
-    cut_rows(rowstr, r0, rows, nr, opts->wave_rows, t->rrow);
+    spmv_parallel_for(rows, 2048, pass_weigh, &c);
+    if (c.bad) {
+        rc = c.bad == 1 ? -2 : -1;
+        goto out;
+    }
+
+    /*
+     * Row blocks per group: in proportion to the group's entries (groups of 5 and of 4 stripes must not get
+     * the same number of workgroups: the larger ones would run a quarter longer), at least what the
+     * accumulators demand, no more waves than rows; the largest remainders take what is left of the target.
+     */
+    {
+        int64_t total = 0;
+        for (int g = 0; g < NG; ++g) {
+            const uint32_t *w = c.wgt + (size_t)g * rows;
+            int64_t e = 0;
+            for (int r = 0; r < rows; ++r)
+                e += w[r];
+            gent[g] = e;
+            total += e;
+        }
+        const int target = opts->target_wgs < 1 ? 1 : opts->target_wgs;
+        const int64_t per_block = (int64_t)WPB * opts->wave_rows;
+        const int nb_min = (int)((rows + per_block - 1) / per_block);
+        int nb_max = rows / WPB; /* no point in more waves than rows */
+        if (nb_max < nb_min)
+            nb_max = nb_min;
+        int used = 0;
+        for (int g = 0; g < NG; ++g) {
+            int nb = total > 0 ? (int)((int64_t)target * gent[g] / total) : target / NG;
+            nb = nb < nb_min ? nb_min : (nb > nb_max ? nb_max : nb);
+            gnb[g] = nb;
+            used += nb;
+        }
+        while (used < target) { /* largest remainder first; ties to the lower group: deterministic */
+            int best = -1;
+            double best_rem = -1.0;
+            for (int g = 0; g < NG; ++g) {
+                if (gnb[g] >= nb_max)
+                    continue;
+                const double rem = (total > 0 ? (double)target * (double)gent[g] / (double)total : 0.0) - gnb[g];
+                if (rem > best_rem)
+                    best_rem = rem, best = g;
+            }
+            if (best < 0)
+                break;
+            gnb[best]++;
+            ++used;
+        }
+        t->n_wg = used;
+        t->n_ranges = used * WPB;
+    }
+    const int nr = t->n_ranges;
+    if ((int64_t)nr * GM > ((int64_t)1 << 26)) {
+        rc = -2;
+        goto out;
+    }
+    c.tsize = (int64_t *)malloc((size_t)nr * GM * sizeof(int64_t));
+    c.rfill = (int64_t *)calloc((size_t)nr, sizeof(int64_t));
+    t->rrow = (int32_t *)calloc((size_t)nr * 2, sizeof(int32_t));
+    t->wgd = (int32_t *)calloc((size_t)t->n_wg * 4, sizeof(int32_t));
+    t->tptr = (int32_t *)calloc((size_t)nr * ((size_t)GM + 1), sizeof(int32_t));
+    if (!c.tsize || !c.rfill || !t->rrow || !t->wgd || !t->tptr)
+        goto out;
+    {
+        int q = 0;
+        for (int g = 0; g < NG; ++g) {
+            cut_rows(c.wgt + (size_t)g * rows, rows, gnb[g] * WPB, opts->wave_rows, t->rrow + (size_t)q * WPB * 2);
+            for (int rb = 0; rb < gnb[g]; ++rb, ++q) {
+                t->wgd[4 * q + 0] = c.gs0[g];
+                t->wgd[4 * q + 1] = c.gs0[g + 1];
+                t->wgd[4 * q + 2] = g;
+                t->wgd[4 * q + 3] = rb;
+            }
+        }
+        t->NB = 0;
+        for (int g = 0; g < NG; ++g)
+            t->NB = gnb[g] > t->NB ? gnb[g] : t->NB;
+    }
+    free(c.wgt);
+    c.wgt = NULL;
+
     spmv_parallel_for(nr, 1, pass_count, &c);
     if (c.bad) {
         rc = c.bad == 1 ? -2 : -1;
         goto out;
     }
 
-    /* tile starts in stream order: stripe group, row block, wave, stripe of the group */
+    /* tile starts in stream order: workgroup (g-major), wave, stripe of the group */
     {
         int64_t total = 0, fillers = 0, longest = 0, ntiles = 0;
-        for (int u = 0; u < nr; ++u)
+        for (int u = 0; u < nr; ++u) {
             fillers += c.rfill[u];
-        for (int g = 0; g < t->NG; ++g) {
-            const int s0 = (int)((int64_t)g * S / t->NG), s1 = (int)((int64_t)(g + 1) * S / t->NG);
-            for (int u = 0; u < nr; ++u) { /* u = rb * WPB + w */
-                int32_t *tp = t->tptr + ((size_t)g * nr + u) * ((size_t)t->GM + 1);
-                for (int si = 0; si <= t->GM; ++si) {
-                    if (total > 0x7fffffff - 65536) {
-                        rc = -2;
-                        goto out;
-                    }
-                    tp[si] = (int32_t)total;
-                    if (s0 + si < s1) {
-                        const int64_t len = c.tsize[(size_t)u * S + s0 + si];
-                        total += len;
-                        longest = len > longest ? len : longest;
-                        ++ntiles;
-                    }
+            const int32_t *d = t->wgd + (size_t)(u / WPB) * 4;
+            const int ns = d[1] - d[0];
+            int32_t *tp = t->tptr + (size_t)u * ((size_t)GM + 1);
+            for (int si = 0; si <= GM; ++si) {
+                if (total > 0x7fffffff - 65536) {
+                    rc = -2;
+                    goto out;
+                }
+                tp[si] = (int32_t)total;
+                if (si < ns) {
+                    const int64_t len = c.tsize[(size_t)u * GM + si];
+                    total += len;
+                    longest = len > longest ? len : longest;
+                    ++ntiles;
                 }
             }
         }
@@ -405,7 +609,7 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
         goto out;
     rc = 0;
 out:
-    free(c.tsize), free(c.rfill), free(c.sg), free(c.ssi);
+    free(c.tsize), free(c.rfill), free(c.sg), free(c.gs0), free(c.wgt), free(gnb), free(gent);
     if (rc != 0)
         spmv_striped_free(t);
     return rc;

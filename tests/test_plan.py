@@ -229,10 +229,11 @@ def test_tiled_rejects_unrepresentable_chunks(lib):
 class StripedHost(ctypes.Structure):
     _fields_ = [("elem", ctypes.c_int), ("W", ctypes.c_int), ("S", ctypes.c_int), ("WPB", ctypes.c_int),
                 ("EPL", ctypes.c_int), ("NB", ctypes.c_int), ("NG", ctypes.c_int), ("GM", ctypes.c_int),
-                ("n_ranges", ctypes.c_int), ("cap", ctypes.c_int), ("skewed", ctypes.c_int),
+                ("n_wg", ctypes.c_int), ("n_ranges", ctypes.c_int), ("cap", ctypes.c_int), ("skewed", ctypes.c_int),
                 ("n_packed", ctypes.c_int64), ("n_dummies", ctypes.c_int64), ("max_tile", ctypes.c_int64),
                 ("val", ctypes.c_void_p), ("col", ctypes.POINTER(ctypes.c_uint16)),
-                ("tptr", ctypes.POINTER(ctypes.c_int32)), ("rrow", ctypes.POINTER(ctypes.c_int32))]
+                ("tptr", ctypes.POINTER(ctypes.c_int32)), ("rrow", ctypes.POINTER(ctypes.c_int32)),
+                ("wgd", ctypes.POINTER(ctypes.c_int32))]
 
 
 class StripedOpts(ctypes.Structure):
@@ -254,31 +255,39 @@ def striped_build(lib, rs, ci, a, xbytes=65536, wpb=8, wgs=6, wave_rows=128, gro
 
 def striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6, wave_rows=128, groups=0):
     """Runs csrc/spmv_striped.c, checks the invariants k_striped relies on, and evaluates the layout on the CPU
-    the way the kernel walks it: workgroup (stripe group, row block), wave, stripe after stripe of the group; rows
-    are recovered by counting row-end flags, row sums accumulate across the stripes of a group, the groups'
-    partial sums are added in group order."""
+    the way the kernel walks it: workgroup (stripe group, row block of that group), wave, stripe after stripe of the
+    group; rows are recovered by counting row-end flags, row sums accumulate across the stripes of a group, the
+    groups' partial sums are added in group order."""
     rows = rs.size - 1
     rc, t = striped_build(lib, rs, ci, a, xbytes, wpb, wgs, wave_rows, groups)
     if rc != 0:
         return rc, None
     nr = t.n_ranges
-    assert nr == t.NB * t.WPB and t.GM == -(-t.S // t.NG) and 1 <= t.NG <= t.S
-    ntp = t.NG * nr * (t.GM + 1)
-    tptr = np.ctypeslib.as_array(t.tptr, (ntp,)).astype(np.int64).reshape(t.NG, nr, t.GM + 1)
-    rrow = np.ctypeslib.as_array(t.rrow, (nr + 1,)).astype(np.int64)
+    assert nr == t.n_wg * t.WPB and t.GM == -(-t.S // t.NG) and 1 <= t.NG <= t.S
+    tptr = np.ctypeslib.as_array(t.tptr, (nr * (t.GM + 1),)).astype(np.int64).reshape(nr, t.GM + 1)
+    rrow = np.ctypeslib.as_array(t.rrow, (nr * 2,)).astype(np.int64).reshape(nr, 2)
+    wgd = np.ctypeslib.as_array(t.wgd, (t.n_wg * 4,)).astype(np.int64).reshape(t.n_wg, 4)
     col = np.ctypeslib.as_array(t.col, (t.n_packed + 1,)).astype(np.int64)
     ctype = ctypes.c_double if a.dtype == np.float64 else ctypes.c_float
     val = np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctype)), (t.n_packed + 1,))
     sub = 64 * t.EPL
-    assert rrow[0] == 0 and rrow[-1] == rows and np.all(np.diff(rrow) >= 0) and np.all(np.diff(rrow) <= wave_rows)
     assert np.all(tptr % sub == 0) and np.all(np.diff(tptr.ravel()) >= 0) and tptr.ravel()[-1] == t.n_packed
-    if rows >= nr:
-        assert np.all(np.diff(rrow) >= 1)  # no idle wave while rows last
+    assert np.all(rrow[:, 1] >= rrow[:, 0]) and np.all(rrow[:, 1] - rrow[:, 0] <= wave_rows)
+    # every group tiles the rows completely, in order, with its own cuts; workgroups are listed group-major
+    assert np.all(np.diff(wgd[:, 2]) >= 0) and wgd[0, 2] == 0 and wgd[-1, 2] == t.NG - 1
+    for g in range(t.NG):
+        qs = np.nonzero(wgd[:, 2] == g)[0]
+        assert qs.size >= 1 and np.array_equal(wgd[qs, 3], np.arange(qs.size)) and qs.size <= t.NB
+        assert np.all(wgd[qs, 0] == g * t.S // t.NG) and np.all(wgd[qs, 1] == (g + 1) * t.S // t.NG)
+        rr = rrow[qs[0] * t.WPB:(qs[-1] + 1) * t.WPB]
+        assert rr[0, 0] == 0 and rr[-1, 1] == rows and np.array_equal(rr[1:, 0], rr[:-1, 1])
+        if rows >= rr.shape[0]:
+            assert np.all(rr[:, 1] > rr[:, 0])  # no idle wave while rows last
     # undo the lane interleave of the values inside each sub-window
     G = 16 // a.dtype.itemsize
     e = np.arange(t.n_packed, dtype=np.int64)
-    rr = e % sub
-    phys = e // sub * sub + (rr % t.EPL) // G * (64 * G) + (rr // t.EPL) * G + (rr % t.EPL) % G
+    rr_ = e % sub
+    phys = e // sub * sub + (rr_ % t.EPL) // G * (64 * G) + (rr_ // t.EPL) * G + (rr_ % t.EPL) % G
     val = val[:t.n_packed][phys]
     flags = col[:t.n_packed] >> 15
     assert flags.sum() == t.S * rows  # exactly one row end per (stripe, row)
@@ -286,41 +295,43 @@ def striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=6, wave_rows=128
     assert t.cap - 1 == zero_col and t.W <= zero_col
     partial = np.zeros((t.NG, rows), a.dtype)
     n_fill = 0
-    for g in range(t.NG):
-        s0, s1 = g * t.S // t.NG, (g + 1) * t.S // t.NG
-        for u in range(nr):
-            nrows = int(rrow[u + 1] - rrow[u])
+    for q in range(t.n_wg):
+        s0, s1, g = int(wgd[q, 0]), int(wgd[q, 1]), int(wgd[q, 2])
+        for w in range(t.WPB):
+            u = q * t.WPB + w
+            nrows = int(rrow[u, 1] - rrow[u, 0])
             acc = np.zeros(nrows, a.dtype)
             for si in range(t.GM + 1):
                 if s0 + si >= s1:
-                    assert tptr[g, u, si] == tptr[g, u, min(s1 - s0, t.GM)]  # past the group's last stripe: the end
+                    assert tptr[u, si] == tptr[u, min(s1 - s0, t.GM)]  # past the group's last stripe: the end
                     continue
                 s = s0 + si
                 row = 0
                 run = a.dtype.type(0)
-                for q in range(int(tptr[g, u, si]), int(tptr[g, u, si + 1])):
-                    c = int(col[q])
+                for p in range(int(tptr[u, si]), int(tptr[u, si + 1])):
+                    c = int(col[p])
                     lc = c & 0x7fff
                     if lc >= t.W:  # a filler or a pad: times the zeroed last element of the LDS buffer, never x
-                        assert lc == zero_col and val[q] == 0
+                        assert lc == zero_col and val[p] == 0
                         n_fill += c >> 15
                         xv = a.dtype.type(0)
                     else:
                         assert s * t.W + lc < x.size
                         xv = x[s * t.W + lc]
-                    run = run + val[q] * xv
+                    run = run + val[p] * xv
                     if c >> 15:
                         acc[row] = acc[row] + run
                         row += 1
                         run = a.dtype.type(0)
-                assert row == nrows, (g, u, si, row, nrows)
-            partial[g, rrow[u]:rrow[u + 1]] = acc
+                assert row == nrows, (q, w, si, row, nrows)
+            partial[g, rrow[u, 0]:rrow[u, 1]] = acc
     assert n_fill == t.n_dummies
     y = partial[0].copy()
     for g in range(1, t.NG):
         y = y + partial[g]
-    geo = dict(W=t.W, S=t.S, NB=t.NB, NG=t.NG, GM=t.GM, WPB=t.WPB, n_packed=t.n_packed, n_dummies=t.n_dummies,
-               max_tile=t.max_tile, skewed=t.skewed)
+    tiles = np.diff(tptr, axis=1)
+    geo = dict(W=t.W, S=t.S, NB=t.NB, NG=t.NG, GM=t.GM, WPB=t.WPB, n_wg=t.n_wg, n_packed=t.n_packed,
+               n_dummies=t.n_dummies, max_tile=t.max_tile, skewed=t.skewed, tiles=tiles, wgd=wgd)
     lib.spmv_striped_free.argtypes = [ctypes.POINTER(StripedHost)]
     lib.spmv_striped_free(ctypes.byref(t))
     return 0, (y, geo)
@@ -348,9 +359,8 @@ def test_striped_layout(lib, oracle, dtype):
             assert geo["S"] == -(-int(ci.max()) // geo["W"]) and (geo["W"] + unit) * a.dtype.itemsize <= 65536
             assert geo["W"] % unit == 0
             assert geo["W"] - -(-int(ci.max()) // geo["S"]) < unit  # equal stripes, rounded up to 16 bytes of x
-            assert geo["NB"] * geo["WPB"] * 128 >= rows  # every wave range fits the accumulators
             if groups == 0:
-                assert geo["NG"] * geo["NB"] <= max(6, -(-rows // (8 * 128)))
+                assert geo["n_wg"] <= max(6, geo["NG"] * -(-rows // (8 * 128)))
             if groups == 1:
                 assert geo["NG"] == 1
             tol = (np.diff(rs) + geo["S"] + 2) * eps * absum
@@ -367,7 +377,6 @@ def test_striped_wave_ranges_respect_the_accumulator_limit(lib):
     rc, res = striped_emulate(lib, rs, ci, a, x, wgs=4, wave_rows=256)
     assert rc == 0
     y, geo = res
-    assert geo["NB"] * geo["WPB"] * 256 >= lens.size
     ref = np.array([np.dot(a[rs[r] - 1:rs[r + 1] - 1], x[ci[rs[r] - 1:rs[r + 1] - 1] - 1]) for r in range(lens.size)])
     assert np.allclose(y, ref, rtol=1e-12, atol=1e-12)
 
@@ -392,8 +401,9 @@ assert rc == 0
 h = hashlib.sha256()
 h.update(np.ctypeslib.as_array(t.col, (t.n_packed,)).tobytes())
 h.update(np.ctypeslib.as_array(ctypes.cast(t.val, ctypes.POINTER(ctypes.c_double)), (t.n_packed,)).tobytes())
-h.update(np.ctypeslib.as_array(t.tptr, (t.NG * t.n_ranges * (t.GM + 1),)).tobytes())
-h.update(np.ctypeslib.as_array(t.rrow, (t.n_ranges + 1,)).tobytes())
+h.update(np.ctypeslib.as_array(t.tptr, (t.n_ranges * (t.GM + 1),)).tobytes())
+h.update(np.ctypeslib.as_array(t.rrow, (t.n_ranges * 2,)).tobytes())
+h.update(np.ctypeslib.as_array(t.wgd, (t.n_wg * 4,)).tobytes())
 print(h.hexdigest(), t.n_packed, t.n_dummies)
 """
 
@@ -412,3 +422,22 @@ def test_striped_layout_does_not_depend_on_the_thread_count():
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.strip())
     assert outs[0] == outs[1] == outs[2] and len(outs[0].split()[0]) == 64
+
+
+def test_striped_groups_balance_their_workgroups(lib):
+    """Stripes that do not divide into the groups: groups of 3 stripes and of 2.  Each group cuts the rows by ITS
+    entries and gets row blocks in proportion to them, so the longest workgroup is within a few per cent of the
+    average (with the same cuts and the same block count for every group the larger groups ran half as long again),
+    and within a group every wave's stream is as long as its neighbours'."""
+    rng = np.random.default_rng(8)
+    rows, cols = 6000, 8190 * 12
+    rs, ci, a = matgen.random_csr(8, rows, cols, 60, spread=0.3)
+    x = rng.standard_normal(int(ci.max()))
+    rc, res = striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=40, wave_rows=256, groups=5)
+    assert rc == 0
+    y, geo = res
+    assert geo["S"] % geo["NG"] != 0  # uneven groups, or the test tests nothing
+    per_wave = geo["tiles"].sum(axis=1).reshape(geo["n_wg"], geo["WPB"])  # entries streamed per wave
+    per_wg = per_wave.max(axis=1)
+    assert per_wg.max() <= 1.12 * per_wg.mean(), (per_wg.max(), per_wg.mean())
+    assert 36 <= geo["n_wg"] <= 40
