@@ -133,7 +133,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):  # untimed, exactly as many as the line reports
+    # untimed: a fixed pre-warm (the first dozen passes over a freshly uploaded layout run 5-10 % slower, class D most:
+    # profiles/r02_kbench_npb_shapes_steady_state.log), then the W warm-up steps asked for; the line reports both
+    PREWARM = 12
+    for _ in range(PREWARM + args.warmup):
         dm.spmv_device(dx, dy)
     be.synchronize(device)
     barrier()
@@ -274,6 +277,9 @@ def main():
             "parallelism": "1 GPU" if n_gpus == 1 else
                            "block-row partition over %d GPUs (equal nnz), x replicated, no collective" % n_gpus,
             "rank_ms_per_step": rank_ms,
+            "untimed_steps_before_timing": PREWARM + args.warmup,
+            "prewarm": "%d untimed steps before the %d warm-up steps: the first passes over a freshly uploaded layout are slower" % (
+                PREWARM, args.warmup),
         },
         "roofline": {
             "bound": "hbm",

@@ -94,8 +94,8 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped
      * blocks; within that, as many stripe groups as keep the workgroups within the target (every workgroup
      * resident at once: one 160-KiB workgroup per CU), because fewer stripes per workgroup mean fewer
      * re-stagings of x and longer uninterrupted streams, and the partial sums that more groups cost are
-     * few: class C 10 groups x 25 row blocks (12 MB of partials beside a 373 MB stream), a class D row
-     * block of 187 500 rows 21 groups of 4-5 stripes, all of class D 2 groups x 128 row blocks.
+     * few (class C: 12 MB of partials beside a 373 MB stream).  This is the upper bound; the builder lowers it
+     * where the groups' row blocks would not fit the target (choose_groups).
      */
     const int target = o->target_wgs < 1 ? 1 : o->target_wgs;
     const int64_t per_block = (int64_t)o->wpb * o->wave_rows;
