@@ -135,8 +135,12 @@ def main():
 
     # untimed: a fixed pre-warm (the first dozen passes over a freshly uploaded layout run 5-10 % slower, class D most:
     # profiles/r02_kbench_npb_shapes_steady_state.log), then the W warm-up steps asked for; the line reports both
-    PREWARM = 12
-    for _ in range(PREWARM + args.warmup):
+    PREWARM = 0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.05 or PREWARM < 12:  # ~50 ms of back-to-back products: clocks and caches settled
+        dm.time_device(dx, dy, 12)
+        PREWARM += 12
+    for _ in range(args.warmup):
         dm.spmv_device(dx, dy)
     be.synchronize(device)
     barrier()
@@ -278,8 +282,9 @@ def main():
                            "block-row partition over %d GPUs (equal nnz), x replicated, no collective" % n_gpus,
             "rank_ms_per_step": rank_ms,
             "untimed_steps_before_timing": PREWARM + args.warmup,
-            "prewarm": "%d untimed steps before the %d warm-up steps: the first passes over a freshly uploaded layout are slower" % (
-                PREWARM, args.warmup),
+            "prewarm": "%d untimed steps (50 ms of back-to-back products) before the %d warm-up steps: the first hundred launches after an "
+                       "upload run 3-10 %% slower (profiles/r02_kbench_npb_shapes_steady_state.log, r02_kbench_ab_priority_rotation.log)" % (
+                           PREWARM, args.warmup),
         },
         "roofline": {
             "bound": "hbm",
@@ -367,13 +372,13 @@ def main():
         dxd = be.malloc(xd.nbytes, device)
         dyd = be.malloc(md.rows * 8, device)
         be.h2d(dxd, xd, device)
-        dmd.time_device(dxd, dyd, 12)  # untimed: the first dozen passes over a freshly uploaded 7-GB layout run 5-10 % slower
+        dmd.time_device(dxd, dyd, 40)  # untimed (~50 ms): the first passes over a freshly uploaded 7-GB layout run 5-10 % slower
         ksteps = 20                    # (tools/jobs/r2_xcd.sh: 1245 us for the first 30 launches, 1175 us from then on)
         msd = dmd.time_device(dxd, dyd, ksteps) / ksteps
         line["scale_ref"] = {
             "workload": "NPB CG class D, whole matrix on 1 GPU (what the N > 1 runs partition)",
             "value": round(2.0 * md.nnz / (msd * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "ms_per_step": round(msd, 6),
-            "steps": ksteps, "warmup": 12, "nnz": int(md.nnz), "plan": pkg.abi.PLAN_NAMES[infd["plan"]],
+            "steps": ksteps, "warmup": 40, "nnz": int(md.nnz), "plan": pkg.abi.PLAN_NAMES[infd["plan"]],
             "roofline_frac": round(infd["algorithmic_bytes"] / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": infd["algorithmic_bytes"], "generated_s": round(t_gen, 1),
             "launches_per_step": infd["n_launches"], "workgroups": infd["n_blocks"],

@@ -158,9 +158,13 @@ int spmv_hip_synchronize(int device);
 /* Experiment switches used by tools/kbench.py (not a stable interface; they affect matrices and
  * plans created afterwards): 0 XCD-contiguous block order of k_stream / k_striped (default 1); 1 non-temporal
  * loads of a/colidx (0); 2-4 TILED geometry (waves per workgroup, LDS bytes per stripe, workgroups
- * aimed for); 5 register sets of k_tiled / k_striped; 9, 11, 12 STRIPED geometry (workgroups aimed
+ * aimed for); 5 register sets of k_tiled / k_striped; 6 k_striped ablation / diagnostic bits (timing experiments: results are
+ * wrong when set); 9, 11, 12 STRIPED geometry (workgroups aimed
  * for, stripe groups (0 = choose), most rows per wave range). */
 void spmv_hip_set_tuning(int key, int value);
+/* Experiments: per-workgroup 100-MHz clock stamps (entry, first x stripe staged, wave 0 done, last wave done) of the
+ * last k_striped launch made under tuning key 6 = 64; n <= 4096 values.  tools/kbench.py --stamps prints a summary. */
+int spmv_hip_debug_stamps(int device, unsigned long long *out, int n);
 
 /* ---- ABI-path control ------------------------------------------------------ */
 void spmv_hip_get_stats(spmv_hip_stats *out);

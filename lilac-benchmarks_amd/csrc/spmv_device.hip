@@ -998,6 +998,17 @@ void spmv_hip_host_free(void *p) { spmvd_host_free(p); }
 int spmv_hip_host_register(void *p, size_t bytes) { return spmvd_host_register(p, bytes); }
 void spmv_hip_host_unregister(void *p) { spmvd_host_unregister(p); }
 
+extern "C" int spmvk_striped_stamps(unsigned long long *out, int n);
+/* experiments: the per-workgroup clock stamps a k_striped launch leaves under tuning key 6 value 64 (100-MHz ticks:
+ * entry, first stripe staged, wave 0 done, last wave done) */
+int spmv_hip_debug_stamps(int device, unsigned long long *out, int n)
+{
+    if (use_device(device))
+        return -1;
+    HIPCHK(hipDeviceSynchronize(), return -1);
+    return spmvk_striped_stamps(out, n);
+}
+
 void spmv_hip_set_tuning(int key, int value)
 {
     if (key == 2)

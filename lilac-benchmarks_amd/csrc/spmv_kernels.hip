@@ -51,6 +51,10 @@ int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx       
 int g_tune_abl = 0;     /* k_striped ablation bits (timing experiments only; results are wrong when set) */
 int g_tune_tile_k = 0;  /* register sets of k_tiled (2,4,6,8; default 4) / k_striped (2,3,4; default 2) */
 
+/* diagnostic stamps of k_striped (ablation bit 64; tools/kbench.py --stamps): per workgroup the 100-MHz wall clock at
+ * entry, after the first stripe of x is staged, and when wave 0 is done; never written by a normal launch */
+__device__ unsigned long long g_striped_stamps[1024 * 4];
+
 /* ---- 16-byte vector types --------------------------------------------------- */
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -657,6 +661,8 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
     if (q >= nwg)
         return; /* the whole workgroup */
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if ((abl & 64) && tid == 0 && q < 1024)
+        g_striped_stamps[4 * q] = __builtin_amdgcn_s_memrealtime();
     const int s0 = __builtin_amdgcn_readfirstlane(wgd[4 * q]), s1 = __builtin_amdgcn_readfirstlane(wgd[4 * q + 1]);
     const int g = __builtin_amdgcn_readfirstlane(wgd[4 * q + 2]);
     const int u = q * WPB + w; /* wave range */
@@ -802,6 +808,8 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
             if (tid == NT - 1) /* the thread that wrote the buffer's last 16 bytes: fillers and pads multiply with 0 */
                 s_x[W - 1] = (T)0;
             wg_barrier_lds();
+            if ((abl & 64) && si == 0 && tid == 0 && q < 1024)
+                g_striped_stamps[4 * q + 1] = __builtin_amdgcn_s_memrealtime();
         }
         /* ---- the wave's tile ---- */
         const int Pend = __builtin_amdgcn_readfirstlane(tp[si + 1]);
@@ -809,6 +817,22 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
         row = 0, flushed = 0, carry = (T)0;
         int j = 0;
         for (; j + R <= nsub; j += R) {
+            if (!(abl & 128)) {
+                /*
+                 * The four waves that share a SIMD (w, w+4, w+8, w+12) take turns at every priority, a turn = 4
+                 * sub-windows.  Left alone, the arbiter favours the older wave: wave 0 of a class C workgroup was
+                 * done after 51 us and the last wave after 65 (clock stamps, tools/kbench.py --stamps), and a CU
+                 * whose waves retire one by one has ever fewer bytes in flight for its last quarter.  Worth 0.4-1.1 %
+                 * (12 interleaved A/B rounds: class C 75.8 against 76.4 us, B 28.7 / 29.0, a class D row block
+                 * 177.6 / 178.3); tuning key 6 bit 128 switches it off.
+                 */
+                switch (((j >> 2) + (w >> 2)) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 sub_window(set[r], P + (j + r) * SUB);
@@ -834,6 +858,12 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
         __builtin_amdgcn_wave_barrier();
     }
 
+    if ((abl & 64) && lane == 0 && q < 1024) { /* wave 0: its own end; wave WPB - 1: the last wave's (a proxy for the workgroup's) */
+        if (w == 0)
+            g_striped_stamps[4 * q + 2] = __builtin_amdgcn_s_memrealtime();
+        if (w == WPB - 1)
+            g_striped_stamps[4 * q + 3] = __builtin_amdgcn_s_memrealtime();
+    }
     /* ---- the group is done: acc[k] of lane l is the sum of local row 64 k + l over the group's stripes ---- */
     const bool folded = dotv != nullptr; /* kernel-uniform */
     T dot = (T)0;
@@ -1091,6 +1121,14 @@ void spmvk_set_tuning(int key, int value)
         g_tune_tile_k = value;
     else if (key == 6)
         g_tune_abl = value;
+}
+
+/* copies the diagnostic stamps of the last k_striped launch with ablation bit 64 (experiments only) */
+int spmvk_striped_stamps(unsigned long long *out, int n)
+{
+    if (n > 1024 * 4)
+        n = 1024 * 4;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_striped_stamps), (size_t)n * sizeof(unsigned long long));
 }
 
 int spmvk_ordered(const spmv_dev_csr *m, const void *x, void *y, void *stream)

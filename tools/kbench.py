@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--swrows", type=int, default=1024, help="STRIPED: most rows per wave range (multiple of 64, <= 1024)")
     ap.add_argument("--abl", default="0", help="STRIPED: comma list of ablation bit masks to time after the real kernel (1 no fold, "
                                               "2 plain partial stores, 4 no accumulator updates, 8 no ring writes); results are wrong")
+    ap.add_argument("--stamps", action="store_true", help="STRIPED: one extra launch that leaves per-workgroup clock stamps; prints "
+                                                          "when workgroups start, have x staged and finish")
+    ap.add_argument("--ab-rounds", type=int, default=0, help="STRIPED: time the real kernel and the --abl masks in turn, this many rounds")
+    ap.add_argument("--stamps-abl", type=int, default=0, help="further tuning-key-6 bits for the stamped launch")
     ap.add_argument("--plans", default="", help="comma list of plan names to run (default all)")
     args = ap.parse_args()
     pkg = pkgload.load_package()
@@ -115,7 +119,37 @@ def main():
                     print("%-10s %-4s %-8s %-9s %10.2f %10.1f %8.1f   launches=%d" % (
                         case, dts, pname, tun, ms * 1e3, i2["algorithmic_bytes"] / ms / 1e6,
                         2.0 * i2["nnz"] / ms / 1e6, i2["n_launches"]), flush=True)
-                    if pname == "striped":
+                    if pname == "striped" and args.stamps:
+                        import ctypes
+                        be.set_tuning(6, 64 | args.stamps_abl)
+                        dm.time_device(dx, dy, 1)
+                        be.set_tuning(6, 0)
+                        nwg = min(i2["n_blocks"], 1024)
+                        buf = (ctypes.c_ulonglong * (4 * nwg))()
+                        be.lib.spmv_hip_debug_stamps.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+                        assert be.lib.spmv_hip_debug_stamps(0, buf, 4 * nwg) == 0
+                        st = np.array(buf[:], dtype=np.float64).reshape(nwg, 4) * 0.01  # us
+                        t0 = st[:, 0].min()
+                        q = lambda v: "min %.2f med %.2f max %.2f" % (v.min(), np.median(v), v.max())  # noqa: E731
+                        print("#   stamps (us after the first workgroup's entry): entry %s | x staged %s | wave 0 done %s | last wave done %s"
+                              % (q(st[:, 0] - t0), q(st[:, 1] - t0), q(st[:, 2] - t0), q(st[:, 3] - t0)), flush=True)
+                        print("#   staging takes %s us; workgroups end within %.2f us of each other" % (
+                            q(st[:, 1] - st[:, 0]), st[:, 3].max() - st[:, 3].min()), flush=True)
+                    if pname == "striped" and args.ab_rounds > 0:
+                        # interleaved A/B (boxes drift by a few per cent within a run): the real kernel and every mask, in turn
+                        masks = [0] + [int(v) for v in args.abl.split(",") if int(v)]
+                        acc = {mk: [] for mk in masks}
+                        for _ in range(args.ab_rounds):
+                            for mk in masks:
+                                be.set_tuning(6, mk)
+                                dm.time_device(dx, dy, 2)
+                                acc[mk].append(dm.time_device(dx, dy, 20) / 20 * 1e3)
+                        be.set_tuning(6, 0)
+                        for mk in masks:
+                            v = np.array(acc[mk])
+                            print("#   A/B %d rounds x 20 launches, tuning-6 mask %3d: mean %.2f us  median %.2f  std %.2f" % (
+                                args.ab_rounds, mk, v.mean(), np.median(v), v.std()), flush=True)
+                    elif pname == "striped":
                         for ab in [int(v) for v in args.abl.split(",") if int(v)]:
                             be.set_tuning(6, ab)
                             dm.time_device(dx, dy, 3)
