@@ -457,7 +457,8 @@ static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_
 /* spmvd_set_relayout(0): matrices created from now on get no re-laid-out copy (STRIPED / TILED) from
  * the automatic choice -- for the ABI path when a matrix keeps changing between calls and the
  * conversion would be paid every time (spmv_harness.c) */
-static int g_relayout = 1;
+static thread_local int g_relayout = 1; /* per calling thread: the ABI path's upload threads set their own, a direct-API
+                                           user creating matrices on another thread is not affected */
 extern "C" void spmvd_set_relayout(int on) { g_relayout = on ? 1 : 0; }
 
 /* geometry knobs of the STRIPED plan (experiments through spmv_hip_set_tuning keys 9, 11, 12) */

@@ -696,7 +696,7 @@ typedef struct upload_job {
     int p;
     const void *a;
     const int *rowstr, *colidx;
-    int rows, elem, cols_hint, ok;
+    int rows, elem, cols_hint, relayout, ok;
     char err[400];
     pthread_t th;
 } upload_job;
@@ -707,6 +707,7 @@ static void *upload_part(void *v)
     upload_job *j = (upload_job *)v;
     slot *sl = j->sl;
     const int p = j->p, dev = sl->part_dev[p];
+    spmvd_set_relayout(j->relayout); /* a per-thread setting of the device layer */
     sl->part[p] = spmv_hip_matrix_create(j->a, j->rowstr, j->colidx, j->rows, j->elem, dev, sl->bounds[p],
                                          sl->bounds[p + 1], sl->nparts == 1 ? 0 : j->cols_hint);
     int ok = sl->part[p] != NULL;
@@ -743,7 +744,6 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
     spmv_hip_partition_rows(rowstr, rows, sl->nparts, sl->bounds);
 
     const int churn = G.cache == CACHE_OFF || churning(a, rowstr, colidx);
-    spmvd_set_relayout(!churn);
     /* the length of x: max(colidx) over the WHOLE matrix (libspmv/gpu.c:217-223); one part finds it on the device
      * while it uploads, several parts need it up front so that they can upload side by side */
     int cols = 0;
@@ -757,7 +757,7 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
         sl->part_dev[p] = p % G.ndev;
         memset(&job[p], 0, sizeof job[p]);
         job[p].sl = sl, job[p].p = p, job[p].a = a, job[p].rowstr = rowstr, job[p].colidx = colidx;
-        job[p].rows = rows, job[p].elem = elem, job[p].cols_hint = cols;
+        job[p].rows = rows, job[p].elem = elem, job[p].cols_hint = cols, job[p].relayout = !churn;
     }
     /*
      * One host thread per part: each uploads its row block to its device, re-lays it out and allocates its x / y
@@ -775,7 +775,7 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
         pthread_join(job[p].th, NULL);
     for (int p = started + 1; p < sl->nparts; ++p) /* threads that could not be started */
         upload_part(&job[p]);
-    spmvd_set_relayout(1);
+    spmvd_set_relayout(1); /* the calling thread ran part 0 */
     for (int p = 0; p < sl->nparts; ++p)
         if (!job[p].ok)
             die("matrix upload failed (part %d of %d): %s", p, sl->nparts, job[p].err);

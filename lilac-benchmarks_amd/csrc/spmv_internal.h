@@ -220,7 +220,7 @@ void spmvd_host_unregister(void *p);
 int spmvd_copy_h2d_async(int device, void *dst_dev, const void *src, size_t bytes);
 int spmvd_copy_d2h_async(int device, void *dst, const void *src_dev, size_t bytes);
 int spmvd_stream_sync(int device);
-/* 0: the automatic plan choice of matrices created from now on skips the re-laid-out plans */
+/* 0: the automatic plan choice of matrices created BY THE CALLING THREAD from now on skips the re-laid-out plans */
 void spmvd_set_relayout(int on);
 /* zero-copy: the device-side address of pinned host memory (hipHostMalloc'ed or registered), NULL
  * when it has none; and a word copy kernel on the device's stream whose source may be such memory */

@@ -41,7 +41,7 @@ struct spmv_hip_matrix {
     int *col;    /* 1-based copies of the block */
     void *val;
 };
-static int g_relayout = 1;
+static _Thread_local int g_relayout = 1;
 int mock_creates, mock_relayout_creates;
 void spmvd_set_relayout(int on) { g_relayout = on; }
 
