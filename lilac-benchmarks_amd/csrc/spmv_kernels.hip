@@ -89,17 +89,26 @@ __device__ __forceinline__ float fmadd(float a, float b, float c) { return __bui
 /* ---- DPP cross-lane adds ------------------------------------------------------ */
 /* One DPP move of a 32- or 64-bit value; lanes whose source is disabled by
  * row_mask read 0 (old = 0, bound_ctrl off). */
+/* A shift over all four rows (row_shr:n = 0x111..0x11f, wave_shr:1 = 0x138, row_mask 0xf) leaves no lane without a
+ * defined result when bound_ctrl makes the lanes without a source read 0: then the move needs no "old" operand and the
+ * compiler no v_mov 0 in front of it (two per 64-bit move, ten per sub-window of k_striped). */
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_mov_bits(int v)
+{
+    if constexpr (ROW_MASK == 0xf && ((CTRL >= 0x111 && CTRL <= 0x11f) || CTRL == 0x138))
+        return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+    else
+        return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float v)
 {
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+    return __builtin_bit_cast(float, dpp_mov_bits<CTRL, ROW_MASK>(__builtin_bit_cast(int, v)));
 }
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov(double v)
 {
     long long b = __builtin_bit_cast(long long, v);
     int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    lo = dpp_mov_bits<CTRL, ROW_MASK>(lo);
+    hi = dpp_mov_bits<CTRL, ROW_MASK>(hi);
     long long r = ((long long)hi << 32) | (unsigned int)lo;
     return __builtin_bit_cast(double, r);
 }
@@ -584,7 +593,7 @@ done:
  */
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_mov(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+    return dpp_mov_bits<CTRL, ROW_MASK>(v);
 }
 
 /* one step of the inclusive segmented scan: (v, f) <- (prev o cur) with prev fetched by DPP */
