@@ -174,6 +174,36 @@ def test_striped_geometries(pkg, backend, oracle, dtype):
         backend.set_tuning(9, 256)
 
 
+def test_timed_call_traffic_and_pinned_memory(pkg, backend, oracle):
+    """spmv_hip_time_call: what an ABI call moves around the kernels (libspmv/gpu.c:264,285) -- x from (pinned) host
+    memory, the product, the block's y slice straight to its row offset of the caller's vector -- as bench.py times it at
+    N > 1.  Two row blocks of one matrix write their slices into ONE host vector: the host gather, no collective."""
+    rs, ci, a = matgen.npb_like(44, 9000, 150)
+    rows = 9000
+    x = np.random.default_rng(44).standard_normal(rows)
+    y = np.full(rows, np.nan)
+    pinned = [v for v in (x, y) if backend.host_register(v)]
+    bounds = backend.partition_rows(rs, rows, 2)
+    try:
+        for p in range(2):
+            r0, r1 = int(bounds[p]), int(bounds[p + 1])
+            m = backend.matrix(a, rs, ci, rows, row_begin=r0, row_end=r1)
+            dx = backend.malloc(x.nbytes)
+            dy = backend.malloc((r1 - r0) * 8 + 16)
+            try:
+                ms = m.time_call(x, y[r0:r1], dx, dy, 3)
+                assert ms > 0.0
+            finally:
+                m.close()
+                backend.free(dx)
+                backend.free(dy)
+    finally:
+        for v in pinned:
+            backend.host_unregister(v)
+    y_ref = oracle.spmv(a, x, rs, ci, rows)
+    assert_close_rows(y, y_ref, oracle.absum(a, x, rs, ci, rows), np.diff(rs), np.float64, "host-gathered y")
+
+
 def test_rowstr_not_starting_at_one(backend, oracle):
     """native-impl.c indexes a[rowstr[i]-1]: a CSR whose rowstr[0] > 1 skips a prefix of a/colidx."""
     rs, ci, a = matgen.random_csr(41, 500, 300, 12)
