@@ -8,6 +8,7 @@
  *   spmvdrv pagerank <backend.so> <file.mtx | rmat:SCALE:EF | grid:N> [iters] [runs]
  *   spmvdrv parboil  <backend.so> <matrix.mtx> <vector.bin> [out file] [golden .out]
  *   spmvdrv pathsample <backend.so> <nmin> [npfold] [max neighbours] [seed]
+ *   spmvdrv reload   <backend.so> <cycles>      dlopen / multiply / dlclose / write to the arrays, repeated
  *
  * The backend is loaded like pagerank/main.cpp:13-45 does (dlopen RTLD_NOW + dlsym).
  */
@@ -61,13 +62,63 @@ static int load_graph(const char *spec, csr_d *m, int as_bfs)
     return mm_read_csr(spec, m);
 }
 
+/*
+ * pagerank/main.cpp:13-45 loads the backend in a constructor and dlclose()s it in the destructor while the caller's
+ * arrays are still alive.  A backend that caches them (and write-protects them to notice edits) has to let go of
+ * them at dlclose: after it, the caller writes to every array, and then loads the library again.
+ */
+static int reload_cycles(const char *path, int cycles)
+{
+    csr_d m;
+    if (graph_grid2d(600, 600, &m)) /* 360 000 rows, 1.8 M nonzeros: rowstr/colidx/a are 350-3500 pages each */
+        return 4;
+    double *x = malloc(((size_t)m.cols + 2) * sizeof(double)), *y = malloc(((size_t)m.rows + 2) * sizeof(double));
+    for (int i = 0; i < m.cols + 2; ++i)
+        x[i] = 1.0 + (double)(i % 7);
+    for (int c = 0; c < cycles; ++c) {
+        void *lib = dlopen(path, RTLD_NOW);
+        if (!lib) {
+            fprintf(stderr, "cycle %d: couldn't load %s\n%s\n", c, path, dlerror());
+            return 2;
+        }
+        d_harness_fn fn = (d_harness_fn)dlsym(lib, "spmv_harness_");
+        if (!fn)
+            return 3;
+        for (int rep = 0; rep < 3; ++rep) /* the second and third call find the cached copy */
+            fn(y, m.a, x, m.rowstr, m.colidx, &m.rows);
+        int64_t bad = 0;
+        for (int r = 0; r < m.rows; ++r) {
+            double s = 0.0; /* small integers times c+1: exact in any order */
+            for (int j = m.rowstr[r] - 1; j < m.rowstr[r + 1] - 1; ++j)
+                s += m.a[j] * x[m.colidx[j] - 1];
+            bad += s != y[r];
+        }
+        dlclose(lib);
+        /* the library is gone (or at least told to go): all three arrays must be ordinary writable memory again */
+        for (int64_t j = 0; j < m.nnz; j += 512) {
+            m.a[j] *= 2.0;
+            m.colidx[j] = m.colidx[j];
+        }
+        for (int r = 0; r <= m.rows; r += 1024)
+            m.rowstr[r] = m.rowstr[r];
+        printf("cycle %d: %lld rows differ; arrays written after dlclose\n", c, (long long)bad);
+        if (bad)
+            return 6;
+    }
+    free(x), free(y);
+    csr_d_free(&m);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 4) {
-        fprintf(stderr, "Usage: %s sb|bfs|pagerank|parboil|pathsample <backend.so> <input> [...]\n", argv[0]);
+        fprintf(stderr, "Usage: %s sb|bfs|pagerank|parboil|pathsample|reload <backend.so> <input> [...]\n", argv[0]);
         return 1;
     }
     const char *bench = argv[1];
+    if (!strcmp(bench, "reload"))
+        return reload_cycles(argv[2], atoi(argv[3]));
     void *lib = dlopen(argv[2], RTLD_NOW);
     if (!lib) {
         fprintf(stderr, "Couldn't load %s\n%s\n", argv[2], dlerror());

@@ -822,6 +822,18 @@ def test_cli_drivers_on_the_hip_backend(pkg):
     assert out.returncode == 0 and "rows=14 nnz=239" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("cache", ["mprotect", "compare"])
+def test_backend_can_be_unloaded_and_loaded_again(pkg, cache):
+    """pagerank/main.cpp:25-30 dlclose()s the backend while its arrays are alive: `spmvdrv reload` loads the library,
+    multiplies (device path, arrays cached and -- under mprotect -- write-protected), unloads it, writes to all three
+    matrix arrays and starts over, three times.  A guard left behind would kill the process at the first write."""
+    env = dict(os.environ, SPMV_HIP_DISPATCH="device", SPMV_HIP_CACHE=cache, SPMV_HIP_STATS="1")
+    out = subprocess.run([pkg.lib_path("spmvdrv"), "reload", pkg.lib_path(), "3"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("0 rows differ; arrays written after dlclose") == 3, out.stdout + out.stderr
+
+
 def test_sparsebench_170_full_size(pkg, backend, oracle):
     """BASELINE configs[2] at its full size: crsmat170u has 170^3 = 4 913 000 rows (big_gen.py:60-83,
     seeded stand-in); one product against the oracle row by row, then linearity A(x+2z) = Ax + 2Az,
