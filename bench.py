@@ -41,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+MEASURED_READ_CEILING_GBS = 6386.6
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -299,6 +300,10 @@ def main():
             "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
             "launch_us": round(launch_ms * 1e3, 3),
             "scope": "rank 0's row block" if n_gpus > 1 else "whole matrix",
+            # context, not the contract's fraction: what a kernel that only READS memory reaches on an MI355X
+            # (tools/streambench.hip, 24 KiB per workgroup: profiles/r01_streambench_read_ceilings.log)
+            "measured_read_ceiling": {"GB/s": MEASURED_READ_CEILING_GBS, "frac_of_it": round(achieved / MEASURED_READ_CEILING_GBS, 4),
+                                      "source": "profiles/r01_streambench_read_ceilings.log (stored figure)"},
         },
     }
 
