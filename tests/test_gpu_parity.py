@@ -1026,6 +1026,29 @@ def test_bench_line_has_the_contract_keys():
     assert d["npb_cg"]["verified"] and d["npb_cg_device"]["verified"]
 
 
+def test_every_plan_is_reproducible_also_after_a_rebuild(pkg, backend):
+    """No atomics anywhere and layouts built by a fixed rule: on NPB class B every plan returns the same bits 25 times
+    in a row, and a second matrix object -- CSR copy, row statistics and the re-laid-out STRIPED / TILED arrays built
+    again, by the multi-threaded builders -- returns them too (what `tools/soak_determinism.py` soaks for longer)."""
+    m = pkg.npb.NpbMatrix("B")
+    x = np.random.default_rng(3).standard_normal(m.na + 2)
+    plans = [(pkg.PLAN_AUTO, 0), (pkg.PLAN_STRIPED, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0),
+             (pkg.PLAN_VECTOR, 16), (pkg.PLAN_ORDERED, 0)]
+    first = {}
+    for build in range(2):
+        dm = backend.matrix(m.a, m.rowstr, m.colidx, m.rows)
+        try:
+            for plan in plans:
+                dm.set_plan(*plan)
+                for rep in range(25 if build == 0 else 3):
+                    y = bits(dm.spmv_host(x))
+                    if plan not in first:
+                        first[plan] = y
+                    assert np.array_equal(y, first[plan]), (plan, build, rep)
+        finally:
+            dm.close()
+
+
 def test_class_c_full_size_fp32(pkg, backend, oracle):
     """The FP32 twin (f_spmv_harness_'s kernels) on the full class C pattern: ORDERED and TILED bit-identical to
     the oracle's float loop, every other plan inside the reordering bound."""
