@@ -65,6 +65,8 @@ def main():
                                                           "when workgroups start, have x staged and finish")
     ap.add_argument("--ab-rounds", type=int, default=0, help="STRIPED: time the real kernel and the --abl masks in turn, this many rounds")
     ap.add_argument("--stamps-abl", type=int, default=0, help="further tuning-key-6 bits for the stamped launch")
+    ap.add_argument("--stamps-launches", type=int, default=0, help="STRIPED: this many further stamped launches; says how much of a "
+                    "workgroup's lateness comes back launch after launch (its place on the chip) and how much is chance")
     ap.add_argument("--plans", default="", help="comma list of plan names to run (default all)")
     args = ap.parse_args()
     pkg = pkgload.load_package()
@@ -135,6 +137,33 @@ def main():
                               % (q(st[:, 0] - t0), q(st[:, 1] - t0), q(st[:, 2] - t0), q(st[:, 3] - t0)), flush=True)
                         print("#   staging takes %s us; workgroups end within %.2f us of each other" % (
                             q(st[:, 1] - st[:, 0]), st[:, 3].max() - st[:, 3].min()), flush=True)
+                        if args.stamps_launches > 0:
+                            ends = []
+                            for _ in range(args.stamps_launches):
+                                be.set_tuning(6, 64 | args.stamps_abl)
+                                dm.time_device(dx, dy, 1)
+                                be.set_tuning(6, 0)
+                                assert be.lib.spmv_hip_debug_stamps(0, buf, 4 * nwg) == 0
+                                s2 = np.array(buf[:], dtype=np.float64).reshape(nwg, 4) * 0.01
+                                ends.append(s2[:, 3] - s2[:, 0].min())
+                            ends = np.array(ends)                      # [launch, workgroup]
+                            rel = ends - ends.mean(axis=1, keepdims=True)  # lateness against the launch's mean end
+                            per_wg = rel.mean(axis=0)
+                            print("#   %d stamped launches: a workgroup's end against its launch's mean: std over everything %.2f us, "
+                                  "std of the per-workgroup means %.2f us (what its place explains), mean launch length %.2f, "
+                                  "mean of the last end %.2f, of the median end %.2f" % (
+                                      args.stamps_launches, rel.std(), per_wg.std(), ends.max(axis=1).mean(), ends.max(axis=1).mean(),
+                                      np.median(ends, axis=1).mean()), flush=True)
+                            per_xcd = max(1, (nwg + 7) // 8)
+                            xcd = np.arange(nwg) // per_xcd
+                            print("#   mean lateness by index // %d (us): %s" % (per_xcd, " ".join("%+.2f" % per_wg[xcd == k].mean() for k in range(8))), flush=True)
+                            print("#   mean lateness by index %% 8 (us):  %s" % " ".join("%+.2f" % per_wg[np.arange(nwg) % 8 == k].mean() for k in range(8)), flush=True)
+                            print("#   (tuning xcd1: index // %d is the XCD; xcd0: index %% 8 is)" % per_xcd, flush=True)
+                            order = np.argsort(per_wg)
+                            print("#   earliest workgroups (index: us): %s" % " ".join("%d:%+.1f" % (i, per_wg[i]) for i in order[:8]), flush=True)
+                            print("#   latest workgroups   (index: us): %s" % " ".join("%d:%+.1f" % (i, per_wg[i]) for i in order[-8:]), flush=True)
+                            if args.stamps_launches >= 40:
+                                print("#   per-workgroup mean lateness, in index order: %s" % " ".join("%+.1f" % v for v in per_wg), flush=True)
                     if pname == "striped" and args.ab_rounds > 0:
                         # interleaved A/B (boxes drift by a few per cent within a run): the real kernel and every mask, in turn
                         masks = [0] + [int(v) for v in args.abl.split(",") if int(v)]
