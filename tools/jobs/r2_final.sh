@@ -22,7 +22,7 @@ print('N1 value', d['value'], 'ms/step', d['ms_per_step'], 'launch_us', d['roofl
 print('npb_cg', d['npb_cg']['mops'], d['npb_cg']['time_s'], d['npb_cg']['us_per_abi_call'], '| device cg', d['npb_cg_device']['mops'])
 print('f32', d['spmv_f32']['us_per_spmv'], d['spmv_f32']['roofline_frac'], '| scale_ref', d['scale_ref']['ms_per_step'], d['scale_ref']['roofline_frac'])
 print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['ms_per_spmv'])
-d=json.load(open('$OUT/bench_n2_rehearsal.json'))
+d=json.loads([l for l in open('$OUT/bench_n2_rehearsal.json') if l.startswith('{')][-1])  # gloo prints to stdout too
 print('N2 rehearsal value', d['value'], d['ms_per_step'], 'gather', d['gather_inclusive']['value'], d['gather_inclusive']['ms_per_step'])
 t=json.load(open('$OUT/pmc_traffic.json')); print(t['hbm_bytes_per_spmv'])
 "
