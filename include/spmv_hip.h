@@ -160,7 +160,8 @@ int spmv_hip_synchronize(int device);
  * loads of a/colidx (0); 2-4 TILED geometry (waves per workgroup, LDS bytes per stripe, workgroups
  * aimed for); 5 register sets of k_tiled / k_striped; 6 k_striped ablation / diagnostic bits (timing experiments: results are
  * wrong when set); 9, 11, 12 STRIPED geometry (workgroups aimed
- * for, stripe groups (0 = choose), most rows per wave range). */
+ * for, stripe groups (0 = choose), most rows per wave range); 14 tests: the next re-layout upload
+ * fails as if the device were out of memory. */
 void spmv_hip_set_tuning(int key, int value);
 /* Experiments: per-workgroup 100-MHz clock stamps (entry, first x stripe staged, wave 0 done, last wave done) of the
  * last k_striped launch made under tuning key 6 = 64; n <= 4096 values.  tools/kbench.py --stamps prints a summary. */

@@ -103,7 +103,8 @@ struct spmv_hip_matrix {
     int *h_rowstr_local = nullptr; /* rows+1 ints, 1-based copy of the block's rowstr (for replans) */
     /* TILED (built on demand from the device CSR copy) */
     bool have_tiled = false;
-    int tiled_rc = 0; /* last build status: 0 ok, -2 not representable */
+    int tiled_rc = 0; /* last build status: 0 ok, -2 not representable, -3 no memory (host or device) for the second
+                         copy -- neither is fatal for an automatic choice: the CSR copy serves --, -1 anything else */
     spmv_dev_tiled dt{};
     size_t tiled_bytes = 0;
     /* STRIPED (built on demand) */
@@ -355,6 +356,9 @@ static int ensure_bins(spmv_hip_matrix *m)
     return 0;
 }
 
+/* tests: the next re-layout upload behaves as if the device were out of memory (tuning key 14) */
+static int g_fail_relayout_alloc = 0;
+
 /*
  * Builds the TILED layout.  host_a / host_col may be the caller's arrays (creation time, `first`
  * = 0-based offset of the block's first entry); when they are NULL the device CSR copy is
@@ -373,7 +377,8 @@ static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_
         if (!tmp_a || !tmp_c) {
             free(tmp_a), free(tmp_c);
             spmv_set_error("out of host memory for the TILED conversion");
-            return -1;
+            m->tiled_rc = -3;
+            return -3;
         }
         hipStream_t st = g_dev[m->device].stream;
         if (m->nnz > 0) {
@@ -402,10 +407,10 @@ static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_
         spmv_tiled_free(&th);
         rc = -2; /* columns are local to the rows: x gathers already hit in cache, STREAM is the better plan */
     }
-    m->tiled_rc = rc;
+    m->tiled_rc = rc == -1 ? -3 : rc;
     if (rc == -1) {
         spmv_set_error("out of host memory for the TILED conversion");
-        return -1;
+        return -3;
     }
     if (rc == -2) {
         spmv_set_error("matrix not representable in the TILED layout (a chunk exceeds 65535 entries) or not suited to it");
@@ -429,11 +434,16 @@ static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_
         e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
+    if (e == hipSuccess && g_fail_relayout_alloc)
+        e = hipErrorOutOfMemory, g_fail_relayout_alloc = 0;
     if (e != hipSuccess) {
         spmv_set_error("TILED upload failed: %s", hipGetErrorString(e));
         (void)hipFree(d_w), (void)hipFree(d_s), (void)hipFree(d_c), (void)hipFree(d_v);
         spmv_tiled_free(&th);
-        return -1;
+        (void)hipGetLastError();
+        /* no room for the second copy: not fatal for an automatic choice, the CSR copy serves (-3) */
+        m->tiled_rc = e == hipErrorOutOfMemory ? -3 : -1;
+        return m->tiled_rc;
     }
     m->dt.wptr = (const int32_t *)d_w;
     m->dt.seg = (const uint16_t *)d_s;
@@ -485,7 +495,8 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         if (!tmp_a || !tmp_c) {
             free(tmp_a), free(tmp_c);
             spmv_set_error("out of host memory for the STRIPED conversion");
-            return -1;
+            m->striped_rc = -3;
+            return -3;
         }
         hipStream_t st = g_dev[m->device].stream;
         if (m->nnz > 0) {
@@ -520,10 +531,10 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         spmv_striped_free(&th);
         rc = -2;
     }
-    m->striped_rc = rc;
+    m->striped_rc = rc == -1 ? -3 : rc;
     if (rc == -1) {
         spmv_set_error("out of host memory for the STRIPED conversion");
-        return -1;
+        return -3;
     }
     if (rc == -2) {
         spmv_set_error("matrix not representable in the STRIPED layout or not suited to it");
@@ -554,12 +565,17 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
+    if (e == hipSuccess && g_fail_relayout_alloc)
+        e = hipErrorOutOfMemory, g_fail_relayout_alloc = 0;
     if (e != hipSuccess) {
         spmv_set_error("STRIPED upload failed: %s", hipGetErrorString(e));
         (void)hipFree(d_t), (void)hipFree(d_r), (void)hipFree(d_c), (void)hipFree(d_v), (void)hipFree(d_p);
         (void)hipFree(d_g);
         spmv_striped_free(&th);
-        return -1;
+        (void)hipGetLastError();
+        /* no room for the second copy: not fatal for an automatic choice, the CSR copy serves (-3) */
+        m->striped_rc = e == hipErrorOutOfMemory ? -3 : -1;
+        return m->striped_rc;
     }
     m->ds.tptr = (const int32_t *)d_t;
     m->ds.rrow = (const int32_t *)d_r;
@@ -725,7 +741,7 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     }
     if (m->plan == SPMV_HIP_PLAN_TILED) {
         int rc = ensure_tiled(m, a, colidx, first, true);
-        if (rc == -2) { /* not representable: the row-segment kernel takes it */
+        if (rc == -2 || rc == -3) { /* not representable, or no memory for a second copy: the row-segment kernel takes it */
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
         } else if (rc) {
@@ -734,7 +750,7 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     }
     if (m->plan == SPMV_HIP_PLAN_STRIPED) {
         int rc = ensure_striped(m, a, colidx, first, true);
-        if (rc == -2) {
+        if (rc == -2 || rc == -3) {
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
         } else if (rc) {
@@ -757,13 +773,13 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
     case SPMV_HIP_PLAN_AUTO:
         spmv_plan_choose(&m->st, m->elem, m->cols, &m->plan, &m->param);
         if (m->plan == SPMV_HIP_PLAN_TILED && ensure_tiled(m, nullptr, nullptr, 0, true)) {
-            if (m->tiled_rc != -2)
+            if (m->tiled_rc != -2 && m->tiled_rc != -3)
                 return -1;
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
         }
         if (m->plan == SPMV_HIP_PLAN_STRIPED && ensure_striped(m, nullptr, nullptr, 0, true)) {
-            if (m->striped_rc != -2)
+            if (m->striped_rc != -2 && m->striped_rc != -3)
                 return -1;
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
@@ -1024,6 +1040,8 @@ void spmv_hip_set_tuning(int key, int value)
         g_stripe_groups = value;
     else if (key == 12 && value >= 64 && value <= SPMV_STRIPE_WAVE_ROWS && value % 64 == 0)
         g_stripe_wave_rows = value;
+    else if (key == 14)
+        g_fail_relayout_alloc = value != 0;
     else
         spmvk_set_tuning(key, value);
 }

@@ -1026,6 +1026,39 @@ def test_bench_line_has_the_contract_keys():
     assert d["npb_cg"]["verified"] and d["npb_cg_device"]["verified"]
 
 
+def test_no_room_for_the_second_copy_is_not_fatal(pkg, backend, oracle):
+    """The re-laid-out copy of a matrix (STRIPED, TILED) is an optimisation next to the CSR copy: when the device has
+    no memory for it, an automatic choice falls back to the CSR kernels and the product is still right; only asking
+    for the plan by name fails.  (The out-of-memory answer is injected with tuning key 14.)"""
+    rs, ci, a = matgen.npb_like(61, 40000, 200)
+    rows = rs.size - 1
+    x = np.random.default_rng(61).standard_normal(rows)
+    y_ref = oracle.spmv(a, x, rs, ci, rows)
+    absum = oracle.absum(a, x, rs, ci, rows)
+    m = backend.matrix(a, rs, ci, rows)
+    try:
+        assert m.info()["plan"] == pkg.PLAN_STRIPED  # what AUTO picks for this shape when there is room
+    finally:
+        m.close()
+    backend.set_tuning(14, 1)
+    m = backend.matrix(a, rs, ci, rows)
+    try:
+        assert m.info()["plan"] == pkg.PLAN_STREAM
+        assert_close_rows(m.spmv_host(x), y_ref, absum, np.diff(rs), np.float64, "fallback at creation")
+        backend.set_tuning(14, 1)
+        with pytest.raises(RuntimeError, match="out of memory|upload failed"):
+            m.set_plan(pkg.PLAN_STRIPED, 0)
+        backend.set_tuning(14, 1)
+        m.set_plan(pkg.PLAN_AUTO, 0)  # the automatic choice again: still no room, still served
+        assert m.info()["plan"] == pkg.PLAN_STREAM
+        m.set_plan(pkg.PLAN_AUTO, 0)  # and with room the layout is built after all
+        assert m.info()["plan"] == pkg.PLAN_STRIPED
+        assert_close_rows(m.spmv_host(x), y_ref, absum, np.diff(rs), np.float64, "striped after the fallback")
+    finally:
+        backend.set_tuning(14, 0)
+        m.close()
+
+
 def test_every_plan_is_reproducible_also_after_a_rebuild(pkg, backend):
     """No atomics anywhere and layouts built by a fixed rule: on NPB class B every plan returns the same bits 25 times
     in a row, and a second matrix object -- CSR copy, row statistics and the re-laid-out STRIPED / TILED arrays built
