@@ -1,4 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/upload
-timeout -k 10 900 python tools/upload_breakdown.py C,D > gpurun_out/upload/breakdown.log 2>&1; echo "rc=$?" >> gpurun_out/upload/breakdown.log
-cat gpurun_out/upload/breakdown.log
+cat /sys/fs/cgroup/cpu.max > gpurun_out/upload/default_threads.log 2>&1
+timeout -k 10 900 python tools/upload_breakdown.py C,D >> gpurun_out/upload/default_threads.log 2>&1
+cat gpurun_out/upload/default_threads.log

@@ -22,7 +22,8 @@ for cls in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["C"]):
     t0 = time.perf_counter()
     rc, t = test_plan.striped_build(lib, m.rowstr, m.colidx, m.a, xbytes=131072, wpb=16, wgs=256, wave_rows=1024, groups=0)
     t1 = time.perf_counter()
-    print("%s host re-layout alone (%d threads): %.3f s  (%d packed entries)" % (cls, min(8, __import__('os').cpu_count()), t1 - t0, t.n_packed))
+    lib.spmv_build_threads.restype = ctypes.c_int
+    print("%s host re-layout alone (%d threads): %.3f s  (%d packed entries)" % (cls, lib.spmv_build_threads(), t1 - t0, t.n_packed))
     n_packed = t.n_packed
     lib.spmv_striped_free.argtypes = [ctypes.POINTER(test_plan.StripedHost)]
     lib.spmv_striped_free(ctypes.byref(t))
