@@ -68,6 +68,8 @@ typedef struct spmv_hip_stats {
     double t_total;         /* s: entry -> return, all calls                                 */
     int64_t host_calls;     /* of `calls`: products dispatched to the host loop (SPMV_HIP_DISPATCH) */
     double t_host;          /* s: spent in those                                             */
+    int64_t value_refreshes; /* cached copies whose VALUES were uploaded again while the sparsity pattern stayed */
+                            /* (only `a` had changed: Pfold.f90:219-223); their time is part of t_upload       */
 } spmv_hip_stats;
 
 /* ---- runtime ------------------------------------------------------------- */
@@ -89,6 +91,13 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
                                         int cols_hint);
 void spmv_hip_matrix_destroy(spmv_hip_matrix *m);
 int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out);
+/*
+ * New values for the same sparsity pattern: copies the block's share of `a` (the array spmv_hip_matrix_create was given,
+ * same base pointer, same layout) into the device copy that exists -- no allocation, no validation, the plan stays.  A
+ * re-laid-out plan (STRIPED / TILED) packs its second copy again, from `colidx` when given (the caller's array, as at
+ * creation) or from the device's CSR copy when NULL.  0 on success.
+ */
+int spmv_hip_matrix_refresh_values(spmv_hip_matrix *m, const void *a, const int *colidx);
 /* Force a plan (tests, benchmarks).  plan_param: lanes for VECTOR (1,2,4,..,64), 0 = default. */
 int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param);
 
@@ -155,17 +164,14 @@ int spmv_hip_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t 
 int spmv_hip_memset(int device, void *dst_dev, int value, size_t bytes);
 int spmv_hip_synchronize(int device);
 
-/* Experiment switches used by tools/kbench.py (not a stable interface; they affect matrices and
- * plans created afterwards): 0 XCD-contiguous block order of k_stream / k_striped (default 1); 1 non-temporal
- * loads of a/colidx (0); 2-4 TILED geometry (waves per workgroup, LDS bytes per stripe, workgroups
- * aimed for); 5 register sets of k_tiled / k_striped; 6 k_striped ablation / diagnostic bits (timing experiments: results are
- * wrong when set); 9, 11, 12 STRIPED geometry (workgroups aimed
- * for, stripe groups (0 = choose), most rows per wave range); 14 tests: the next re-layout upload
- * fails as if the device were out of memory. */
+/* Geometry switches used by tools/kbench.py and tools/shapebench.py (not a stable interface; they affect matrices and
+ * plans created afterwards, and must not change while an upload is in flight): 0 XCD-contiguous block order of
+ * k_stream / k_striped (default 1); 1 non-temporal loads of a/colidx (0); 2-4 TILED geometry (waves per workgroup, LDS
+ * bytes per stripe, workgroups aimed for); 5 register sets of k_tiled; 9, 11, 12 STRIPED geometry (workgroups aimed for,
+ * stripe groups, most rows per wave range; 0 = choose); 15 STRIPED kernel shape (0 = chosen per matrix, 1 = 16 waves x
+ * 128 KiB of x, 2 = 8 waves x 64 KiB).  Diagnostics (ablation bits, clock stamps, fault injection) are not in this
+ * library: they live in the debug build, include/spmv_hip_debug.h. */
 void spmv_hip_set_tuning(int key, int value);
-/* Experiments: per-workgroup 100-MHz clock stamps (entry, first x stripe staged, wave 0 done, last wave done) of the
- * last k_striped launch made under tuning key 6 = 64; n <= 4096 values.  tools/kbench.py --stamps prints a summary. */
-int spmv_hip_debug_stamps(int device, unsigned long long *out, int n);
 
 /* ---- ABI-path control ------------------------------------------------------ */
 void spmv_hip_get_stats(spmv_hip_stats *out);

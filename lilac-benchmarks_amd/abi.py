@@ -34,7 +34,7 @@ class Stats(ctypes.Structure):
         ("calls", ctypes.c_int64), ("uploads", ctypes.c_int64), ("invalidations", ctypes.c_int64),
         ("t_init", ctypes.c_double), ("t_upload", ctypes.c_double), ("t_x_h2d", ctypes.c_double),
         ("t_kernel", ctypes.c_double), ("t_y_d2h", ctypes.c_double), ("t_total", ctypes.c_double),
-        ("host_calls", ctypes.c_int64), ("t_host", ctypes.c_double),
+        ("host_calls", ctypes.c_int64), ("t_host", ctypes.c_double), ("value_refreshes", ctypes.c_int64),
     ]
 
     def as_dict(self):
@@ -69,6 +69,7 @@ class Backend:
         L.spmv_hip_matrix_destroy.restype = None
         L.spmv_hip_matrix_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(Info)]
         L.spmv_hip_matrix_set_plan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.spmv_hip_matrix_refresh_values.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.spmv_hip_spmv_device.argtypes = [ctypes.c_void_p] * 4
         L.spmv_hip_time_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
@@ -224,6 +225,12 @@ class Matrix:
 
     def set_plan(self, plan, param=0):
         if self.be.lib.spmv_hip_matrix_set_plan(self.h, plan, param) != 0:
+            raise RuntimeError(self.be.last_error())
+
+    def refresh_values(self, a, colidx=None):
+        """New values for the same pattern (spmv_hip_matrix_refresh_values); `a` as given at creation."""
+        assert a.dtype == self.dtype
+        if self.be.lib.spmv_hip_matrix_refresh_values(self.h, _ptr(a), _ptr(colidx) if colidx is not None else None) != 0:
             raise RuntimeError(self.be.last_error())
 
     def spmv_device(self, x_dev, y_dev, stream=None):

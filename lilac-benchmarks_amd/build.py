@@ -20,11 +20,11 @@ def _make(directory, *targets):
 
 def build_all(verbose=False):
     """Compile libhip-spmv.so (HIP, gfx950) and the host-side drivers."""
-    out = _make(os.path.join(PKG_DIR, "csrc"))
+    out = _make(os.path.join(PKG_DIR, "csrc"), "all", "debug")
     out += _make(os.path.join(PKG_DIR, "host"))
     if verbose:
         print(out)
-    for f in ("libhip-spmv.so", "libnpbcg.so", "npbcg", "libspmvcallers.so", "spmvdrv"):
+    for f in ("libhip-spmv.so", "libhip-spmv-debug.so", "libnpbcg.so", "npbcg", "libspmvcallers.so", "spmvdrv"):
         if not os.path.exists(lib_path(f)):
             raise RuntimeError("build did not produce " + lib_path(f))
     return LIB_DIR

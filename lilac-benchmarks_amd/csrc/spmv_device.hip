@@ -19,6 +19,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +82,7 @@ struct spmv_hip_matrix {
     int rows = 0;
     int cols = 0;
     int64_t nnz = 0;
+    int64_t first = 0; /* 0-based offset of the block's first entry in the caller's a / colidx */
     int *d_rowptr = nullptr;
     int *d_col = nullptr;
     void *d_val = nullptr;
@@ -110,6 +112,7 @@ struct spmv_hip_matrix {
     /* STRIPED (built on demand) */
     bool have_striped = false;
     bool striped_mostly_filler = false;
+    size_t striped_bytes = 0;
     int striped_rc = 0;
     spmv_dev_striped ds{};
 };
@@ -276,6 +279,8 @@ int spmvd_copy_words_async(int device, void *dst_dev, const void *src_devptr, si
 
 /* ---- matrices ------------------------------------------------------------------- */
 
+static void free_relayouts(spmv_hip_matrix *m);
+
 static void free_plans(spmv_hip_matrix *m)
 {
     if (m->d_blk)
@@ -288,7 +293,20 @@ static void free_plans(spmv_hip_matrix *m)
         (void)hipFree(m->d_partials);
     if (m->d_binrows)
         (void)hipFree(m->d_binrows);
+    free_relayouts(m);
+    m->d_blk = m->d_seg = m->d_lrow = m->d_binrows = nullptr;
+    m->d_partials = nullptr;
+    spmv_plan_stream_free(&m->sp);
+    if (m->have_bins)
+        spmv_plan_bins_free(&m->bp);
+    m->have_bins = false;
+}
+
+/* the second, re-laid-out copies (STRIPED / TILED) */
+static void free_relayouts(spmv_hip_matrix *m)
+{
     if (m->have_striped) {
+        m->device_bytes -= m->striped_bytes;
         (void)hipFree((void *)m->ds.tptr);
         (void)hipFree((void *)m->ds.rrow);
         (void)hipFree((void *)m->ds.wgd);
@@ -299,18 +317,13 @@ static void free_plans(spmv_hip_matrix *m)
         m->have_striped = false;
     }
     if (m->have_tiled) {
+        m->device_bytes -= m->tiled_bytes;
         (void)hipFree((void *)m->dt.wptr);
         (void)hipFree((void *)m->dt.seg);
         (void)hipFree((void *)m->dt.col);
         (void)hipFree((void *)m->dt.val);
         m->have_tiled = false;
     }
-    m->d_blk = m->d_seg = m->d_lrow = m->d_binrows = nullptr;
-    m->d_partials = nullptr;
-    spmv_plan_stream_free(&m->sp);
-    if (m->have_bins)
-        spmv_plan_bins_free(&m->bp);
-    m->have_bins = false;
 }
 
 void spmv_hip_matrix_destroy(spmv_hip_matrix *m)
@@ -356,8 +369,14 @@ static int ensure_bins(spmv_hip_matrix *m)
     return 0;
 }
 
-/* tests: the next re-layout upload behaves as if the device were out of memory (tuning key 14) */
-static int g_fail_relayout_alloc = 0;
+#ifdef SPMV_HIP_DEBUG_BUILD
+/* debug build, tests: the next re-layout upload behaves as if the device were out of memory (tuning key 14); consumed by
+ * exactly one of the upload threads */
+static std::atomic<int> g_fail_relayout_alloc{0};
+static bool take_injected_oom() { return g_fail_relayout_alloc.exchange(0) != 0; }
+#else
+static bool take_injected_oom() { return false; }
+#endif
 
 /*
  * Builds the TILED layout.  host_a / host_col may be the caller's arrays (creation time, `first`
@@ -434,8 +453,8 @@ static int ensure_tiled(spmv_hip_matrix *m, const void *host_a, const int *host_
         e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
-    if (e == hipSuccess && g_fail_relayout_alloc)
-        e = hipErrorOutOfMemory, g_fail_relayout_alloc = 0;
+    if (e == hipSuccess && take_injected_oom())
+        e = hipErrorOutOfMemory;
     if (e != hipSuccess) {
         spmv_set_error("TILED upload failed: %s", hipGetErrorString(e));
         (void)hipFree(d_w), (void)hipFree(d_s), (void)hipFree(d_c), (void)hipFree(d_v);
@@ -471,8 +490,9 @@ static thread_local int g_relayout = 1; /* per calling thread: the ABI path's up
                                            user creating matrices on another thread is not affected */
 extern "C" void spmvd_set_relayout(int on) { g_relayout = on ? 1 : 0; }
 
-/* geometry knobs of the STRIPED plan (experiments through spmv_hip_set_tuning keys 9, 11, 12) */
-static int g_stripe_wgs = SPMV_STRIPE_TARGET_WGS, g_stripe_groups = 0, g_stripe_wave_rows = SPMV_STRIPE_WAVE_ROWS;
+/* geometry knobs of the STRIPED plan (experiments through spmv_hip_set_tuning keys 9, 11, 12, 15); read by the upload
+ * threads of a row partition side by side, so atomics; set them only while no upload is in flight */
+static std::atomic<int> g_stripe_wgs{0}, g_stripe_groups{0}, g_stripe_wave_rows{SPMV_STRIPE_WAVE_ROWS}, g_stripe_shape{0};
 
 /* Builds the STRIPED layout; same conventions as ensure_tiled. */
 static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *host_col, int64_t first,
@@ -514,9 +534,16 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     spmv_striped_host th;
     spmv_striped_opts so;
     spmv_striped_default_opts(&so);
-    so.target_wgs = g_stripe_wgs;
-    so.groups = g_stripe_groups;
-    so.wave_rows = g_stripe_wave_rows;
+    const int shape = g_stripe_shape.load() ? g_stripe_shape.load() : spmv_striped_choose_shape(&m->st, m->elem, m->cols);
+    if (shape == 2) { /* 8 waves over 64-KiB stripes, two workgroups per CU */
+        so.xbytes = SPMV_STRIPE2_XBYTES;
+        so.wpb = SPMV_STRIPE2_WPB;
+        so.target_wgs = 2 * SPMV_STRIPE_TARGET_WGS;
+    }
+    if (g_stripe_wgs.load() > 0)
+        so.target_wgs = g_stripe_wgs.load();
+    so.groups = g_stripe_groups.load();
+    so.wave_rows = g_stripe_wave_rows.load();
     int rc = m->cols < 16 ? -2
                           : spmv_striped_build((const char *)host_a + shift * m->elem, m->h_rowstr_local,
                                                host_col + shift, 0, m->rows, m->cols, m->elem, &so, &th);
@@ -565,8 +592,8 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
-    if (e == hipSuccess && g_fail_relayout_alloc)
-        e = hipErrorOutOfMemory, g_fail_relayout_alloc = 0;
+    if (e == hipSuccess && take_injected_oom())
+        e = hipErrorOutOfMemory;
     if (e != hipSuccess) {
         spmv_set_error("STRIPED upload failed: %s", hipGetErrorString(e));
         (void)hipFree(d_t), (void)hipFree(d_r), (void)hipFree(d_c), (void)hipFree(d_v), (void)hipFree(d_p);
@@ -594,10 +621,11 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     m->ds.EPL = th.EPL;
     m->ds.n_ranges = th.n_ranges;
     m->ds.wave_rows = so.wave_rows;
-    m->ds.xbytes = so.xbytes;
+    m->ds.xbytes = so.xbytes; /* with WPB: which of the two kernel shapes */
     m->ds.rows = m->rows;
     m->ds.cols = m->cols;
-    m->device_bytes += ntp * 4 + ((size_t)th.n_ranges * 2 + 2) * 4 + ((size_t)th.n_wg * 4 + 4) * 4 + n_alloc * (2 + (size_t)m->elem) + pbytes;
+    m->striped_bytes = ntp * 4 + ((size_t)th.n_ranges * 2 + 2) * 4 + ((size_t)th.n_wg * 4 + 4) * 4 + n_alloc * (2 + (size_t)m->elem) + pbytes;
+    m->device_bytes += m->striped_bytes;
     m->have_striped = true;
     spmv_striped_free(&th);
     return 0;
@@ -633,6 +661,7 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     m->elem = elem_size;
     m->rows = row_end - row_begin;
     const int64_t first = (int64_t)rowstr[row_begin] - 1; /* 0-based offset into a / colidx */
+    m->first = first;
     m->nnz = (int64_t)rowstr[row_end] - (int64_t)rowstr[row_begin];
     const size_t n_alloc = (size_t)m->nnz + SPMV_PAD_ELEMS;
 
@@ -761,6 +790,39 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
         FAIL();
 #undef FAIL
     return m;
+}
+
+int spmv_hip_matrix_refresh_values(spmv_hip_matrix *m, const void *a, const int *colidx)
+{
+    if (!m || !a) {
+        spmv_set_error("refresh_values: no matrix or no values");
+        return -1;
+    }
+    if (use_device(m->device))
+        return -1;
+    hipStream_t st = g_dev[m->device].stream;
+    if (m->nnz > 0)
+        HIPCHK(hipMemcpyAsync(m->d_val, (const char *)a + m->first * m->elem, (size_t)m->nnz * m->elem,
+                              hipMemcpyHostToDevice, st),
+               return -1);
+    HIPCHK(hipStreamSynchronize(st), return -1); /* the caller may write `a` again as soon as this returns */
+    if (m->have_striped || m->have_tiled) {
+        /* the re-laid-out copies hold the values in their own order: packed again (the plan is kept when that works) */
+        const bool was_striped = m->plan == SPMV_HIP_PLAN_STRIPED, was_tiled = m->plan == SPMV_HIP_PLAN_TILED;
+        free_relayouts(m);
+        int rc = 0;
+        if (was_striped)
+            rc = ensure_striped(m, colidx ? a : nullptr, colidx, m->first, false);
+        else if (was_tiled)
+            rc = ensure_tiled(m, colidx ? a : nullptr, colidx, m->first, false);
+        if (rc == -2 || rc == -3) { /* cannot happen for a layout that existed a moment ago, short of memory: the CSR kernels serve */
+            m->plan = SPMV_HIP_PLAN_STREAM;
+            m->param = SPMV_STREAM_CAP;
+        } else if (rc) {
+            return -1;
+        }
+    }
+    return 0;
 }
 
 int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
@@ -1015,9 +1077,10 @@ void spmv_hip_host_free(void *p) { spmvd_host_free(p); }
 int spmv_hip_host_register(void *p, size_t bytes) { return spmvd_host_register(p, bytes); }
 void spmv_hip_host_unregister(void *p) { spmvd_host_unregister(p); }
 
+#ifdef SPMV_HIP_DEBUG_BUILD
 extern "C" int spmvk_striped_stamps(unsigned long long *out, int n);
-/* experiments: the per-workgroup clock stamps a k_striped launch leaves under tuning key 6 value 64 (100-MHz ticks:
- * entry, first stripe staged, wave 0 done, last wave done) */
+/* debug build (include/spmv_hip_debug.h): the per-workgroup clock stamps a k_striped<DIAG> launch leaves under tuning
+ * key 6 value 64 (100-MHz ticks: entry, first stripe staged, wave 0 done, last wave done) */
 int spmv_hip_debug_stamps(int device, unsigned long long *out, int n)
 {
     if (use_device(device))
@@ -1025,6 +1088,39 @@ int spmv_hip_debug_stamps(int device, unsigned long long *out, int n)
     HIPCHK(hipDeviceSynchronize(), return -1);
     return spmvk_striped_stamps(out, n);
 }
+
+/* debug build: what each workgroup of a STRIPED layout holds -- per workgroup {first stripe, end stripe, group, entries of
+ * all its waves (pads included), entries of its longest wave, rows}; returns the number of workgroups, -1 on error */
+int spmv_hip_debug_striped_wgs(const spmv_hip_matrix *m, long long *out, int max_wgs)
+{
+    if (!m || !m->have_striped || use_device(m->device))
+        return -1;
+    const spmv_dev_striped &d = m->ds;
+    const size_t ntp = (size_t)d.n_ranges * ((size_t)d.GM + 1);
+    int32_t *tp = (int32_t *)malloc(ntp * 4), *wgd = (int32_t *)malloc((size_t)d.n_wg * 16), *rr = (int32_t *)malloc((size_t)d.n_ranges * 8);
+    if (!tp || !wgd || !rr || hipMemcpy(tp, d.tptr, ntp * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(wgd, d.wgd, (size_t)d.n_wg * 16, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(rr, d.rrow, (size_t)d.n_ranges * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        free(tp), free(wgd), free(rr);
+        return -1;
+    }
+    const int n = d.n_wg < max_wgs ? d.n_wg : max_wgs;
+    for (int q = 0; q < n; ++q) {
+        long long all = 0, longest = 0, rows = 0;
+        for (int w = 0; w < d.WPB; ++w) {
+            const size_t u = (size_t)q * d.WPB + w;
+            const long long len = (long long)tp[u * (d.GM + 1) + d.GM] - tp[u * (d.GM + 1)];
+            all += len;
+            longest = len > longest ? len : longest;
+            rows += rr[2 * u + 1] - rr[2 * u];
+        }
+        out[6 * q + 0] = wgd[4 * q], out[6 * q + 1] = wgd[4 * q + 1], out[6 * q + 2] = wgd[4 * q + 2];
+        out[6 * q + 3] = all, out[6 * q + 4] = longest, out[6 * q + 5] = rows;
+    }
+    free(tp), free(wgd), free(rr);
+    return n;
+}
+#endif
 
 void spmv_hip_set_tuning(int key, int value)
 {
@@ -1034,14 +1130,18 @@ void spmv_hip_set_tuning(int key, int value)
         spmv_tiled_set_xbytes(value);
     else if (key == 4)
         spmv_tiled_set_blocks(value);
-    else if (key == 9 && value > 0)
+    else if (key == 9 && value >= 0)
         g_stripe_wgs = value;
     else if (key == 11 && value >= 0)
         g_stripe_groups = value;
     else if (key == 12 && value >= 64 && value <= SPMV_STRIPE_WAVE_ROWS && value % 64 == 0)
         g_stripe_wave_rows = value;
+    else if (key == 15 && value >= 0 && value <= 2)
+        g_stripe_shape = value; /* 0: chosen per matrix, 1: 16 waves x 128 KiB, 2: 8 waves x 64 KiB */
+#ifdef SPMV_HIP_DEBUG_BUILD
     else if (key == 14)
         g_fail_relayout_alloc = value != 0;
+#endif
     else
         spmvk_set_tuning(key, value);
 }

@@ -55,10 +55,14 @@
  *                      recognised with dladdr) are pinned in place once, everything else goes
  *                      through pinned staging buffers; register: pin whatever the caller passes
  *                      (only safe if the caller never frees it); pageable: plain hipMemcpy
- *   SPMV_HIP_DISPATCH = auto (default) | device | host
+ *   SPMV_HIP_DISPATCH = auto (default) | calibrated | device | host
  *                      auto: a product the host finishes sooner than a PCIe round trip goes to a plain sequential loop in
  *                      this library (dispatch_host below; precedent: libspmv/mkl.c:30, mkl-model.c:152-165), and the HIP
- *                      context is not created before a matrix is worth it; device / host force one side.  A machine
+ *                      context is not created before a matrix is worth it -- a pure function of the shapes multiplied so
+ *                      far, so the same run makes the same choices on every host; calibrated: the same rule with the host
+ *                      loop's rate (measured on the products it runs anyway) and the PCIe round trip (measured when the
+ *                      context is created) of THIS machine instead of the built-in constants, at the price of choices that
+ *                      can differ from run to run near the boundary; device / host force one side.  A machine
  *                      without a GPU aborts at the first call whatever this says: the host loop is a dispatch target on
  *                      a GPU machine, not a fallback.
  *   SPMV_HIP_STATS   = 1: summary on stderr at exit; 2: also synchronise
@@ -96,7 +100,12 @@ typedef struct guard {
     char *lo, *hi;           /* protected interior pages [lo,hi), lo==hi when none     */
     size_t head_n, tail_n;   /* bytes of the partial first / last page                  */
     unsigned char *head, *tail; /* saved copies of those bytes                            */
+    volatile sig_atomic_t armed; /* [lo,hi) is read-only and a write into it faults       */
+    volatile sig_atomic_t dirty; /* 0, GUARD_WRITTEN or GUARD_EXPOSED                      */
 } guard;
+/* why a guard no longer vouches for its array: a write faulted in it, or its pages went writable together with a
+ * neighbour's (another cached matrix guards the same pages) and what happened to them since is unknown */
+enum { GUARD_WRITTEN = 1, GUARD_EXPOSED = 2 };
 
 typedef struct slot {
     int used;
@@ -114,11 +123,17 @@ typedef struct slot {
     int part_dev[MAX_PARTS];
     void *dx[MAX_PARTS];     /* device x per part (cols elements)                       */
     void *dy[MAX_PARTS];     /* device y per part (rows of the part)                    */
-    guard g[3];
-    volatile sig_atomic_t armed;
-    volatile sig_atomic_t dirty;
+    guard g[3];              /* a, rowstr, colidx                                        */
+    int uncacheable;         /* memory that cannot be protected: uploaded on every call  */
+    int protect;             /* how its arrays are watched: 1 page protection, 2 saved copies, 0 not at all (pointer policy) */
     uint64_t last_use;
     int64_t uses;            /* products this copy has served                            */
+    /* the values of a cached matrix may change while its sparsity pattern stays (PATHSAMPLE's PFOLD rewrites the
+     * array in the `a` position before every call, Pfold.f90:219-223): see refresh_values() */
+    int64_t uses_since_refresh; /* products since the values were last uploaded                          */
+    int values_volatile;     /* the values change every call: no guard on `a`, they are uploaded each call      */
+    int probing;             /* `a` was re-armed to find out whether it still changes                           */
+    int64_t volatile_calls, probe_every;
 } slot;
 
 static struct {
@@ -133,6 +148,8 @@ static struct {
     slot slots[MAX_SLOTS];
     uint64_t tick;
     slot *last;
+    int calibrated;      /* SPMV_HIP_DISPATCH=calibrated: host rate and PCIe round trip measured, not assumed */
+    double host_ns_per_nnz, pcie_rtt_s;
     /* pinned staging */
     void *xstage, *ystage;
     size_t xstage_n, ystage_n;
@@ -219,72 +236,56 @@ static void guard_unprotect(guard *g)
         mprotect(g->lo, (size_t)(g->hi - g->lo), PROT_READ | PROT_WRITE);
 }
 
-/* Do two slots protect a common page? */
-static int guards_share_pages(const slot *a, const slot *b)
-{
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            if (a->g[i].hi > a->g[i].lo && b->g[j].hi > b->g[j].lo && a->g[i].lo < b->g[j].hi &&
-                b->g[j].lo < a->g[i].hi)
-                return 1;
-    return 0;
-}
-
 /*
- * Takes the page protection off `first` and marks it dirty.  Cached matrices may share host pages
- * (spmv_harness_ and f_spmv_harness_ on one rowstr/colidx, two matrices with one sparsity pattern, the
- * same arrays with another `rows`): making `first`'s pages writable again silently takes the write
- * detection away from every other armed slot that guards one of them, so those are marked dirty too
- * (they upload again at their next call and re-arm), and so on until nothing armed overlaps anything
- * disarmed.  Async-signal-safe: mprotect, pointer compares and plain stores only.
+ * Takes the page protection off `first` (a write faulted in it, or its slot is going away).  Cached matrices may share
+ * host pages (spmv_harness_ and f_spmv_harness_ on one rowstr/colidx, two matrices with one sparsity pattern, the same
+ * arrays with another `rows`): making `first`'s pages writable again silently takes the write detection away from every
+ * other armed guard over one of them, so those are marked GUARD_EXPOSED (their slots upload again at their next call
+ * and re-arm), and so on until no armed guard overlaps a disarmed one.  Guards, not slots, are the unit: a write into
+ * the values of a matrix leaves the guards of its rowstr / colidx -- and every other matrix that shares only those --
+ * armed.  Async-signal-safe: mprotect, pointer compares and plain stores only.
  */
-static void disarm_cascade(slot *first)
+static void disarm_cascade(guard *first, int why)
 {
-    first->dirty = 1;
+    first->dirty = why;
     first->armed = 0;
     for (int changed = 1; changed;) {
         changed = 0;
-        for (int t = 0; t < MAX_SLOTS; ++t) {
-            slot *st = &G.slots[t];
-            if (!st->armed)
+        for (int t = 0; t < MAX_SLOTS * 3; ++t) {
+            guard *gt = &G.slots[t / 3].g[t % 3];
+            if (!gt->armed)
                 continue;
-            for (int u = 0; u < MAX_SLOTS; ++u) {
-                const slot *su = &G.slots[u];
-                if (su != st && su->used && !su->armed && su->dirty && guards_share_pages(st, su)) {
-                    st->dirty = 1;
-                    st->armed = 0;
+            for (int u = 0; u < MAX_SLOTS * 3; ++u) {
+                const guard *gu = &G.slots[u / 3].g[u % 3];
+                if (gu != gt && !gu->armed && gu->dirty && gu->hi > gu->lo && gt->lo < gu->hi && gu->lo < gt->hi) {
+                    gt->dirty = GUARD_EXPOSED;
+                    gt->armed = 0;
                     changed = 1;
                     break;
                 }
             }
         }
     }
-    for (int t = 0; t < MAX_SLOTS; ++t) {
-        slot *st = &G.slots[t];
-        if (!st->used || st->armed || !st->dirty)
+    for (int t = 0; t < MAX_SLOTS * 3; ++t) {
+        guard *gt = &G.slots[t / 3].g[t % 3];
+        if (gt->armed || !gt->dirty || gt->hi <= gt->lo)
             continue;
-        for (int k = 0; k < 3; ++k) {
-            guard_unprotect(&st->g[k]);
-            st->g[k].hi = st->g[k].lo; /* nothing protected any more: later cascades must not see it */
-        }
+        guard_unprotect(gt);
+        gt->hi = gt->lo; /* nothing protected any more: later cascades must not see it */
     }
 }
 
-/* async-signal-safe: only mprotect and stores to sig_atomic_t / slot fields */
+/* async-signal-safe: only mprotect and stores to sig_atomic_t / guard fields */
 static void on_segv(int sig, siginfo_t *si, void *ctx)
 {
     char *addr = (char *)si->si_addr;
-    for (int s = 0; s < MAX_SLOTS; ++s) {
-        slot *sl = &G.slots[s];
-        if (!sl->armed)
-            continue;
-        for (int k = 0; k < 3; ++k) {
-            if (addr >= sl->g[k].lo && addr < sl->g[k].hi) {
-                /* the caller is editing a cached matrix: let the write through and drop the device
-                 * copy at the next call (gpu.c:162-183) -- of every slot that guards these pages */
-                disarm_cascade(sl);
-                return;
-            }
+    for (int t = 0; t < MAX_SLOTS * 3; ++t) {
+        guard *g = &G.slots[t / 3].g[t % 3];
+        if (g->armed && addr >= g->lo && addr < g->hi) {
+            /* the caller is editing a cached matrix: let the write through and refresh the device copy at the next
+             * call (gpu.c:162-183) -- of every slot that guards these pages */
+            disarm_cascade(g, GUARD_WRITTEN);
+            return;
         }
     }
     /* not ours: chain (gpu.c:180-182) */
@@ -314,6 +315,7 @@ static void install_handler(void)
         G.handler_installed = 1;
 }
 
+/* the guard must not be armed any more (disarm_cascade) */
 static void guard_free(guard *g)
 {
     free(g->head);
@@ -371,9 +373,13 @@ static int guard_arm(guard *g, const void *p, size_t bytes, int protect)
     }
     g->lo = (char *)lo;
     g->hi = (char *)hi;
-    if (hi > lo && mprotect((void *)lo, hi - lo, PROT_READ) != 0) {
-        g->lo = g->hi = (char *)e;
-        return -2; /* cannot protect this memory */
+    if (hi > lo) {
+        g->armed = 1; /* before protecting: a fault may come at once */
+        if (mprotect((void *)lo, hi - lo, PROT_READ) != 0) {
+            g->armed = 0;
+            g->lo = g->hi = (char *)e;
+            return -2; /* cannot protect this memory */
+        }
     }
     return 0;
 }
@@ -393,10 +399,11 @@ static void slot_drop(slot *sl)
 {
     if (!sl->used)
         return;
-    if (sl->armed)
-        disarm_cascade(sl); /* slots that share its pages lose their protection with it: they re-upload */
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k) {
+        if (sl->g[k].armed)
+            disarm_cascade(&sl->g[k], GUARD_WRITTEN); /* guards of other slots over its pages lose their protection with it */
         guard_free(&sl->g[k]);
+    }
     for (int p = 0; p < sl->nparts; ++p) {
         spmv_hip_matrix_destroy(sl->part[p]);
         spmv_hip_free(sl->part_dev[p], sl->dx[p]);
@@ -419,9 +426,10 @@ static void print_stats(void)
 {
     const spmv_hip_stats *s = &G.st;
     fprintf(stderr,
-            "libhip-spmv: calls=%lld (host %lld) uploads=%lld invalidations=%lld init=%.3fs upload=%.3fs "
+            "libhip-spmv: calls=%lld (host %lld) uploads=%lld value_refreshes=%lld invalidations=%lld init=%.3fs upload=%.3fs "
             "x_h2d=%.3fs kernel=%.3fs y_d2h=%.3fs host=%.3fs total=%.3fs\n",
-            (long long)s->calls, (long long)s->host_calls, (long long)s->uploads, (long long)s->invalidations,
+            (long long)s->calls, (long long)s->host_calls, (long long)s->uploads, (long long)s->value_refreshes,
+            (long long)s->invalidations,
             s->t_init, s->t_upload, s->t_x_h2d, s->t_kernel, s->t_y_d2h, s->t_host, s->t_total);
 }
 
@@ -469,8 +477,19 @@ static void lib_fini(void)
  * should not pay): the compute driver's device node.  The authoritative check is device_init()'s. */
 static int gpu_node_present(void)
 {
-    const char *fake = getenv("SPMV_HIP_KFD_NODE"); /* tests */
-    return access(fake ? fake : "/dev/kfd", R_OK | W_OK) == 0;
+#ifdef SPMV_TESTING /* the mock-device builds of tests/native have no GPU to find: the test names the node to look for */
+    if (getenv("SPMV_HIP_KFD_NODE"))
+        return access(getenv("SPMV_HIP_KFD_NODE"), R_OK | W_OK) == 0;
+#endif
+    /* a device list emptied on purpose (HIP_VISIBLE_DEVICES= / ROCR_VISIBLE_DEVICES=, or -1) hides every GPU from the
+     * runtime: small products must not run on the host loop in a process whose first large one would then abort */
+    static const char *const lists[] = {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"};
+    for (size_t i = 0; i < sizeof lists / sizeof lists[0]; ++i) {
+        const char *v = getenv(lists[i]);
+        if (v && (!*v || !strcmp(v, "-1")))
+            return 0;
+    }
+    return access("/dev/kfd", R_OK | W_OK) == 0;
 }
 
 /* first call: the environment, and the refusal to run on a machine without a GPU */
@@ -528,8 +547,10 @@ static void lazy_init(void)
             G.dispatch = DISPATCH_DEVICE;
         else if (!strcmp(v, "host"))
             G.dispatch = DISPATCH_HOST;
+        else if (!strcmp(v, "calibrated"))
+            G.calibrated = 1; /* auto, with this host's loop rate and this box's PCIe round trip measured */
         else if (strcmp(v, "auto"))
-            die("SPMV_HIP_DISPATCH=%s: expected auto|device|host", v);
+            die("SPMV_HIP_DISPATCH=%s: expected auto|calibrated|device|host", v);
     }
     if (G.dispatch == DISPATCH_AUTO && (G.plan != SPMV_HIP_PLAN_AUTO || getenv("SPMV_HIP_PARTS") || getenv("SPMV_HIP_DEVICES")))
         G.dispatch = DISPATCH_DEVICE; /* who names a kernel or a row partition wants the device */
@@ -577,6 +598,25 @@ static void device_init(void)
      * registration, so this one frees the device copies BEFORE the runtime goes away (lib_fini runs once) */
     atexit(lib_fini);
     G.dev_inited = 1;
+    if (G.calibrated) {
+        /* the PCIe round trip of a small vector on THIS box: 4 KB down, 4 KB back, through pinned memory; the best of 8 */
+        void *h = spmvd_host_alloc(8192), *d = spmv_hip_malloc(0, 8192);
+        if (h && d) {
+            memset(h, 0, 8192);
+            double best = 1.0;
+            for (int i = 0; i < 8; ++i) {
+                const double t = spmv_now();
+                if (spmvd_copy_h2d_async(0, d, h, 4096) || spmvd_copy_d2h_async(0, (char *)h + 4096, d, 4096) || spmvd_stream_sync(0))
+                    break;
+                const double dt = spmv_now() - t;
+                best = dt < best ? dt : best;
+            }
+            if (best < 1.0)
+                G.pcie_rtt_s = best;
+        }
+        spmvd_host_free(h);
+        spmv_hip_free(0, d);
+    }
     G.st.t_init = spmv_now() - t0;
 }
 
@@ -613,14 +653,19 @@ static void host_spmv_f32(float *ov, const float *a, const float *iv, const int 
 
 /* seconds: the host loop streams about a nonzero per nanosecond while the matrix fits the caches (native.c on the
  * GPU box's EPYC: 2.1 GFLOP/s on class C, out of cache) */
-static double host_estimate(int rows, int64_t nnz) { return 1.0e-9 * (double)nnz + 1.0e-9 * (double)rows + 0.2e-6; }
+static double host_estimate(int rows, int64_t nnz)
+{
+    const double ns = G.calibrated && G.host_ns_per_nnz > 0.0 ? G.host_ns_per_nnz : 1.0; /* measured under =calibrated */
+    return 1.0e-9 * ns * ((double)nnz + (double)rows) + 0.2e-6;
+}
 
 /* seconds for a device call once the matrix is cached: the PCIe round trip of x and y (19 us zero-copy under 1 MB, DMA
  * at ~25 GB/s each way above) plus a kernel that streams 12 bytes per nonzero at a few TB/s */
 static double device_estimate(int rows, int64_t nnz, int elem)
 {
     const double vec = 2.0 * (double)rows * elem; /* x and y; cols is not known before the upload: square */
-    return 19.0e-6 + (vec > 2.0e6 ? vec / 25.0e9 : 0.0) + 5.0e-6 + (double)nnz * (elem + 4) / 3.0e12;
+    const double rtt = G.calibrated && G.pcie_rtt_s > 0.0 ? G.pcie_rtt_s : 19.0e-6;
+    return rtt + (vec > 2.0e6 ? vec / 25.0e9 : 0.0) + 5.0e-6 + (double)nnz * (elem + 4) / 3.0e12;
 }
 
 /*
@@ -647,6 +692,33 @@ static int dispatch_host(int rows, int64_t nnz, int elem)
     if (!G.dev_inited && th < DEVICE_CLASS_SECONDS && G.host_spent + th < HOST_BUDGET_BEFORE_INIT)
         return 1; /* not worth the 0.2 s of context creation yet */
     return 0;
+}
+
+/* what crossing PCIe again costs the values of a cached matrix (pageable memory: ~25 GB/s plus the copy's set-up) */
+static double refresh_estimate(int64_t nnz, int elem) { return 30.0e-6 + (double)nnz * elem / 25.0e9; }
+
+/* the product on the host loop, accounted */
+static void host_product(void *ov, const void *a, const void *iv, const int *rowstr, const int *colidx, int rows,
+                         int64_t nnz, int elem, double t_in)
+{
+    if (elem == 8)
+        host_spmv_f64((double *)ov, (const double *)a, (const double *)iv, rowstr, colidx, rows);
+    else
+        host_spmv_f32((float *)ov, (const float *)a, (const float *)iv, rowstr, colidx, rows);
+    const double dt = spmv_now() - t_in;
+    /*
+     * What a process may spend on the host before it pays for the HIP context is charged in ESTIMATED seconds, a pure
+     * function of the shapes it has multiplied so far (mkl-model.c:152-165 predicts from rows and nnz likewise): the call
+     * at which a process moves from the host loop (the reference's summation order) to the kernels (another order) is
+     * then the same in every run, whatever the host's speed or load.  SPMV_HIP_DISPATCH=calibrated charges measured time.
+     */
+    G.host_spent += G.calibrated ? dt : host_estimate(rows, nnz);
+    if (G.calibrated && nnz >= 20000) { /* long enough for the clock: the host's own rate, smoothed */
+        const double rate = 1e9 * dt / (double)(nnz + rows);
+        G.host_ns_per_nnz = G.host_ns_per_nnz > 0.0 ? 0.75 * G.host_ns_per_nnz + 0.25 * rate : rate;
+    }
+    G.st.calls++, G.st.host_calls++;
+    G.st.t_host += dt, G.st.t_total += dt;
 }
 
 static slot *slot_find(const void *a, const int *rowstr, const int *colidx, int rows, int64_t nnz,
@@ -727,6 +799,40 @@ static void *upload_part(void *v)
     return NULL;
 }
 
+/* the three guarded arrays of a slot: 0 = a, 1 = rowstr, 2 = colidx (the entries the matrix uses) */
+static void slot_array(const slot *sl, int k, const void **p, size_t *bytes)
+{
+    const size_t off = (size_t)(sl->first - 1);
+    if (k == 0)
+        *p = (const char *)sl->a + off * (size_t)sl->elem, *bytes = (size_t)sl->nnz * (size_t)sl->elem;
+    else if (k == 1)
+        *p = sl->rowstr, *bytes = ((size_t)sl->rows + 1) * sizeof(int);
+    else
+        *p = sl->colidx + off, *bytes = (size_t)sl->nnz * sizeof(int);
+}
+
+/* protect: 1 page protection (+ saved partial pages), 2 a full saved copy compared on every call, 0 nothing */
+static void slot_arm_guard(slot *sl, int k, int protect)
+{
+    const void *p;
+    size_t bytes;
+    slot_array(sl, k, &p, &bytes);
+    if (protect == 1)
+        install_handler();
+    const int rc = guard_arm(&sl->g[k], p, bytes, protect);
+    if (rc == -1)
+        die("out of host memory arming write detection");
+    if (rc == -2) {
+        /* memory that cannot be mprotect'ed: be safe, fall back to upload-per-call for it */
+        if (G.verbose)
+            fprintf(stderr, "libhip-spmv: mprotect failed (%s); matrix will not be cached\n", strerror(errno));
+        sl->uncacheable = 1;
+        for (int j = 0; j < 3; ++j)
+            if (sl->g[j].armed)
+                disarm_cascade(&sl->g[j], GUARD_WRITTEN);
+    }
+}
+
 static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *colidx, int rows,
                         int64_t nnz, int elem)
 {
@@ -789,29 +895,9 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
     /* arm write detection AFTER the upload (the copies read the arrays) */
     if (G.cache != CACHE_OFF) {
         /* a churning matrix is compared, not protected: see the note at g_churn */
-        const int protect = G.cache == CACHE_MPROTECT ? (churn ? 2 : 1) : (G.cache == CACHE_COMPARE ? 2 : 0);
-        const size_t off = (size_t)(rowstr[0] - 1);
-        const void *ptrs[3] = {(const char *)a + off * elem, rowstr, colidx + off};
-        const size_t lens[3] = {(size_t)nnz * elem, ((size_t)rows + 1) * sizeof(int),
-                                (size_t)nnz * sizeof(int)};
-        if (protect == 1)
-            install_handler();
-        int ok = 1;
-        sl->armed = protect == 1 ? 1 : 0; /* set before protecting: a fault may come at once */
-        for (int k = 0; k < 3 && ok; ++k) {
-            int rc = guard_arm(&sl->g[k], ptrs[k], lens[k], protect);
-            if (rc == -1)
-                die("out of host memory arming write detection");
-            if (rc == -2)
-                ok = 0;
-        }
-        if (!ok) {
-            /* memory that cannot be mprotect'ed: be safe, fall back to upload-per-call for it */
-            if (G.verbose)
-                fprintf(stderr, "libhip-spmv: mprotect failed (%s); matrix will not be cached\n",
-                        strerror(errno));
-            disarm_cascade(sl);
-        }
+        sl->protect = G.cache == CACHE_MPROTECT ? (churn ? 2 : 1) : (G.cache == CACHE_COMPARE ? 2 : 0);
+        for (int k = 0; k < 3 && !sl->uncacheable; ++k)
+            slot_arm_guard(sl, k, sl->protect);
     }
     G.st.uploads++;
     G.st.t_upload += spmv_now() - t0;
@@ -829,6 +915,49 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
                 elem == 8 ? "f64" : "f32", rows, cols, (long long)nnz, sl->nparts, inf.plan,
                 inf.plan_param, inf.min_row_len, inf.max_row_len, inf.mean_row_len, spmv_now() - t0);
     }
+}
+
+/*
+ * The values of a cached matrix changed and nothing else did (its rowstr / colidx guards still vouch for them): the new
+ * values cross PCIe into the device copy that is there -- no free, no allocation, no validation of the pattern, no new
+ * plan (a re-laid-out plan re-packs its second copy on the device side).  What happens to the watch on `a`:
+ *   - the copy had served SHORT_LIVED_USES products or more: the array is watched again as before;
+ *   - it had not (PATHSAMPLE's PFOLD writes new values before every call, Pfold.f90:219-223): the values are VOLATILE --
+ *     no watch at all (every mprotect() of pages the runtime has registered for its copies makes the driver evict and
+ *     restore the process's queues, tens of milliseconds; a compare reads as many bytes as the copy moves), they are
+ *     simply uploaded on every call; every probe_every-th call a copy of them is kept (CHURN_PROBE_CALLS, doubling up to
+ *     4096 calls) and the next call compares: unchanged values end the volatility.
+ */
+static void refresh_values(slot *sl, const void *a, const int *colidx)
+{
+    const double t0 = spmv_now();
+    for (int p = 0; p < sl->nparts; ++p)
+        if (spmv_hip_matrix_refresh_values(sl->part[p], a, colidx) != 0)
+            die("refreshing the values of a cached matrix failed (part %d of %d): %s", p, sl->nparts, spmv_hip_last_error());
+    const int short_lived = sl->uses_since_refresh < SHORT_LIVED_USES;
+    sl->uses_since_refresh = 0;
+    if (sl->values_volatile) {
+        if (++sl->volatile_calls >= sl->probe_every) { /* look again: keep a copy, the next call compares */
+            sl->values_volatile = 0;
+            sl->probing = 1;
+            slot_arm_guard(sl, 0, 2);
+        }
+    } else {
+        guard_free(&sl->g[0]); /* written, hence disarmed; or a stale saved copy */
+        if (short_lived || sl->probing) {
+            sl->probe_every = sl->probing && sl->probe_every < 4096 ? 2 * sl->probe_every : (sl->probing ? 4096 : CHURN_PROBE_CALLS);
+            sl->values_volatile = 1;
+            sl->volatile_calls = 0;
+            sl->probing = 0;
+        } else {
+            slot_arm_guard(sl, 0, sl->protect);
+        }
+    }
+    G.st.value_refreshes++;
+    G.st.t_upload += spmv_now() - t0;
+    if (G.verbose)
+        fprintf(stderr, "libhip-spmv: values refreshed in %.3f ms%s\n", 1e3 * (spmv_now() - t0),
+                sl->values_volatile ? " (volatile: uploaded on every call)" : "");
 }
 
 /* ---------------------------------------------------------------- pinned transfers */
@@ -1021,54 +1150,69 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
     }
     lazy_init();
     if (dispatch_host(rows, nnz, elem)) {
-        if (elem == 8)
-            host_spmv_f64((double *)ov, (const double *)a, (const double *)iv, rowstr, colidx, rows);
-        else
-            host_spmv_f32((float *)ov, (const float *)a, (const float *)iv, rowstr, colidx, rows);
-        const double dt = spmv_now() - t_in;
-        G.host_spent += dt;
-        G.st.calls++, G.st.host_calls++;
-        G.st.t_host += dt, G.st.t_total += dt;
+        host_product(ov, a, iv, rowstr, colidx, rows, nnz, elem, t_in);
         pthread_mutex_unlock(&g_mu);
         return NULL;
     }
     device_init();
 
     slot *sl = slot_find(a, rowstr, colidx, rows, nnz, elem);
+    int refresh = 0; /* the sparsity pattern of the cached copy stands, its values must be uploaded again */
     if (sl) {
-        int stale = (G.cache == CACHE_OFF) || sl->dirty || sl->first != rowstr[0];
-        if (!stale && (G.cache == CACHE_MPROTECT || G.cache == CACHE_COMPARE))
-            for (int k = 0; k < 3 && !stale; ++k)
-                stale = guard_fragments_changed(&sl->g[k]);
-        if (stale) {
-            if (G.cache != CACHE_OFF) {
+        int full = G.cache == CACHE_OFF || sl->uncacheable || sl->first != rowstr[0];
+        int gd[3] = {0, 0, 0};
+        if (!full && G.cache != CACHE_POINTER)
+            for (int k = 0; k < 3; ++k)
+                gd[k] = sl->g[k].dirty ? (int)sl->g[k].dirty : (guard_fragments_changed(&sl->g[k]) ? GUARD_WRITTEN : 0);
+        if (sl->values_volatile)
+            gd[0] = GUARD_WRITTEN; /* not watched: taken to have changed */
+        /* the caller wrote into the arrays -- as opposed to: a neighbour's write made their pages writable, after which
+         * nothing is known about them; that costs an upload but says nothing about how long this matrix's copies live */
+        const int own = gd[0] == GUARD_WRITTEN || gd[1] == GUARD_WRITTEN || gd[2] == GUARD_WRITTEN || sl->first != rowstr[0];
+        if (gd[1] || gd[2] || gd[0] == GUARD_EXPOSED)
+            full = 1;
+        if (!full && gd[0])
+            refresh = 1;
+        else if (!full && sl->probing) {
+            /* the values were left alone since the look: they have stopped changing; back to the slot's own watch */
+            sl->probing = 0;
+            guard_free(&sl->g[0]);
+            slot_arm_guard(sl, 0, sl->protect);
+            if (sl->uncacheable)
+                full = 1;
+        }
+        if (full) {
+            if (G.cache != CACHE_OFF && own) {
                 G.st.invalidations++;
                 churn_entry *e = churn_find(a, rowstr, colidx, 1);
                 e->short_lived = sl->uses < SHORT_LIVED_USES ? e->short_lived + 1 : 0;
-                if (G.verbose)
-                    fprintf(stderr, "libhip-spmv: host arrays changed, dropping the device copy\n");
             }
+            if (G.verbose && G.cache != CACHE_OFF)
+                fprintf(stderr, "libhip-spmv: %s, dropping the device copy\n",
+                        own ? "host arrays changed" : "pages shared with another cached matrix went writable");
             const double td = spmv_now();
             slot_drop(sl);
             if (G.verbose >= 2)
                 fprintf(stderr, "libhip-spmv: dropped the stale copy in %.3f ms\n", 1e3 * (spmv_now() - td));
             sl = NULL;
+            refresh = 0;
         }
     }
-    if (!sl && G.dispatch == DISPATCH_AUTO && G.nparts == 1) {
+    if (sl && refresh && G.dispatch != DISPATCH_DEVICE && G.nparts == 1 &&
+        host_estimate(rows, nnz) <= refresh_estimate(nnz, elem) + device_estimate(rows, nnz, elem)) {
+        /* new values every call and the host multiplies sooner than they cross PCIe: the copy keeps its pattern and
+         * waits for a call that finds the values as it left them, or for the next refresh */
+        host_product(ov, a, iv, rowstr, colidx, rows, nnz, elem, t_in);
+        pthread_mutex_unlock(&g_mu);
+        return NULL;
+    }
+    if (!sl && G.dispatch != DISPATCH_DEVICE && G.nparts == 1) {
         /* a churning matrix: the host loop, unless another upload is the faster way or it is time to look again */
         churn_entry *e = churn_find(a, rowstr, colidx, 0);
         if (e && e->short_lived >= 2 && e->host_streak < CHURN_PROBE_CALLS &&
             host_estimate(rows, nnz) <= e->last_upload_s + device_estimate(rows, nnz, elem)) {
             e->host_streak++;
-            if (elem == 8)
-                host_spmv_f64((double *)ov, (const double *)a, (const double *)iv, rowstr, colidx, rows);
-            else
-                host_spmv_f32((float *)ov, (const float *)a, (const float *)iv, rowstr, colidx, rows);
-            const double dt = spmv_now() - t_in;
-            G.host_spent += dt;
-            G.st.calls++, G.st.host_calls++;
-            G.st.t_host += dt, G.st.t_total += dt;
+            host_product(ov, a, iv, rowstr, colidx, rows, nnz, elem, t_in);
             pthread_mutex_unlock(&g_mu);
             return NULL;
         }
@@ -1079,9 +1223,12 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
         slot_upload(sl, a, rowstr, colidx, rows, nnz, elem);
         if (G.verbose >= 2)
             fprintf(stderr, "libhip-spmv: victim + upload + arm in %.3f ms\n", 1e3 * (spmv_now() - tu));
+    } else if (refresh) {
+        refresh_values(sl, a, colidx);
     }
     sl->last_use = ++G.tick;
     sl->uses++;
+    sl->uses_since_refresh++;
     if (sl->uses == SHORT_LIVED_USES) { /* this copy has lived: whatever churned before has stopped */
         churn_entry *e = churn_find(a, rowstr, colidx, 0);
         if (e)

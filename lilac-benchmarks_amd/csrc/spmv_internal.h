@@ -127,6 +127,8 @@ void spmv_tiled_set_blocks(int blocks); /* experiments: workgroups aimed for (0 
 #define SPMV_STRIPE_XBYTES 131072  /* bytes of x per stripe (single LDS buffer, one workgroup/CU) */
 #define SPMV_STRIPE_WPB 16         /* waves per workgroup                                        */
 #define SPMV_STRIPE_TARGET_WGS 256 /* workgroups aimed for: one 160-KiB workgroup per CU          */
+#define SPMV_STRIPE2_XBYTES 65536  /* the half-width shape: 64 KiB of x, 8 waves, two workgroups per CU (2 x 80 KiB of LDS) */
+#define SPMV_STRIPE2_WPB 8
 #define SPMV_STRIPE_EPL 4          /* entries per lane per sub-window                            */
 #define SPMV_STRIPE_NACC 16        /* row accumulators per lane                                   */
 #define SPMV_STRIPE_WAVE_ROWS (64 * SPMV_STRIPE_NACC) /* rows a wave can carry across a stripe group */
@@ -136,6 +138,8 @@ typedef struct spmv_striped_opts {
     int target_wgs; /* workgroups aimed for (NB * NG)                                */
     int wave_rows;  /* most rows per wave range (a multiple of 64)                   */
     int groups;     /* stripe groups, 0 = choose                                     */
+    int stripes;    /* column stripes, 0 = choose (the fewest that fit the LDS buffer, or a few more so that
+                       they divide into the groups)                                  */
 } spmv_striped_opts;
 typedef struct spmv_striped_host {
     int elem, W, S, WPB, EPL;
@@ -153,6 +157,9 @@ typedef struct spmv_striped_host {
 } spmv_striped_host;
 
 void spmv_striped_default_opts(spmv_striped_opts *o);
+/* which kernel shape suits the matrix: 1 = 16 waves over 128-KiB stripes (one workgroup per CU), 2 = 8 waves over 64-KiB
+ * stripes (two per CU) */
+int spmv_striped_choose_shape(const spmv_row_stats *st, int elem_size, int cols);
 void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped_opts *o, spmv_striped_host *t);
 /* opts == NULL: the defaults */
 int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,

@@ -48,12 +48,16 @@ namespace {
 /* ---- tuning switches (set through spmvk_set_tuning; experiments only) ------- */
 int g_tune_xcd = 1;     /* give each XCD a contiguous range of row blocks        */
 int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx        */
-int g_tune_abl = 0;     /* k_striped ablation bits (timing experiments only; results are wrong when set) */
-int g_tune_tile_k = 0;  /* register sets of k_tiled (2,4,6,8; default 4) / k_striped (2,3,4; default 2) */
+int g_tune_tile_k = 0;  /* register sets of k_tiled (2,4,6,8; default 4); debug build: of k_striped too (2,3,4; default 2) */
+#ifdef SPMV_HIP_DEBUG_BUILD
+/* The instrumented twin of k_striped (template parameter DIAG) exists in the debug build only (make debug ->
+ * libhip-spmv-debug.so, include/spmv_hip_debug.h): the shipped kernel carries no ablation tests and no stamp stores. */
+int g_tune_abl = 0;     /* k_striped<DIAG> ablation bits (timing experiments only; results are wrong when set) */
 
-/* diagnostic stamps of k_striped (ablation bit 64; tools/kbench.py --stamps): per workgroup the 100-MHz wall clock at
- * entry, after the first stripe of x is staged, and when wave 0 is done; never written by a normal launch */
+/* diagnostic stamps of k_striped<DIAG> (ablation bit 64; tools/kbench.py --stamps): per workgroup the 100-MHz wall clock
+ * at entry, after the first stripe of x is staged, and when wave 0 is done */
 __device__ unsigned long long g_striped_stamps[1024 * 4];
+#endif
 
 /* ---- 16-byte vector types --------------------------------------------------- */
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -646,15 +650,16 @@ template <typename T, int NACC> __device__ __forceinline__ void acc_add(T (&acc)
     acc[ki] = pred ? cur + v : cur;
 }
 
-template <typename T, int WPB, int R, int XT_BYTES, int EPL, int NACC>
+template <typename T, int WPB, int R, int XT_BYTES, int EPL, int NACC, bool DIAG>
 __global__ void __launch_bounds__(WPB * 64, 4)
 k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int *__restrict__ wgd,
           const unsigned short *__restrict__ pcol, const T *__restrict__ pval, const T *__restrict__ x,
           T *__restrict__ y, T *__restrict__ partial, const T *__restrict__ dotv, T *__restrict__ dot_part, int rows,
-          int cols, int NG, int GM, int wcols, int nwg, int per_xcd, int abl)
+          int cols, int NG, int GM, int wcols, int nwg, int per_xcd, int abl_arg)
 {
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E;
+    const int abl = DIAG ? abl_arg : 0; /* the shipped instantiation (DIAG = false) folds every test of it away */
     constexpr int W = XT_BYTES / (int)sizeof(T); /* elements of the LDS buffer; W - 1 is the zero column */
     constexpr int SUB = 64 * EPL;
     constexpr int NT = WPB * 64;
@@ -670,8 +675,10 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
     if (q >= nwg)
         return; /* the whole workgroup */
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if ((abl & 64) && tid == 0 && q < 1024)
+#ifdef SPMV_HIP_DEBUG_BUILD
+    if (DIAG && (abl & 64) && tid == 0 && q < 1024)
         g_striped_stamps[4 * q] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int s0 = __builtin_amdgcn_readfirstlane(wgd[4 * q]), s1 = __builtin_amdgcn_readfirstlane(wgd[4 * q + 1]);
     const int g = __builtin_amdgcn_readfirstlane(wgd[4 * q + 2]);
     const int u = q * WPB + w; /* wave range */
@@ -817,8 +824,10 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
             if (tid == NT - 1) /* the thread that wrote the buffer's last 16 bytes: fillers and pads multiply with 0 */
                 s_x[W - 1] = (T)0;
             wg_barrier_lds();
-            if ((abl & 64) && si == 0 && tid == 0 && q < 1024)
+#ifdef SPMV_HIP_DEBUG_BUILD
+            if (DIAG && (abl & 64) && si == 0 && tid == 0 && q < 1024)
                 g_striped_stamps[4 * q + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
         /* ---- the wave's tile ---- */
         const int Pend = __builtin_amdgcn_readfirstlane(tp[si + 1]);
@@ -867,12 +876,14 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
         __builtin_amdgcn_wave_barrier();
     }
 
-    if ((abl & 64) && lane == 0 && q < 1024) { /* wave 0: its own end; wave WPB - 1: the last wave's (a proxy for the workgroup's) */
+#ifdef SPMV_HIP_DEBUG_BUILD
+    if (DIAG && (abl & 64) && lane == 0 && q < 1024) { /* wave 0: its own end; wave WPB - 1: the last wave's (a proxy for the workgroup's) */
         if (w == 0)
             g_striped_stamps[4 * q + 2] = __builtin_amdgcn_s_memrealtime();
         if (w == WPB - 1)
             g_striped_stamps[4 * q + 3] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
     /* ---- the group is done: acc[k] of lane l is the sum of local row 64 k + l over the group's stripes ---- */
     const bool folded = dotv != nullptr; /* kernel-uniform */
     T dot = (T)0;
@@ -1116,6 +1127,35 @@ int dispatch_vector(const spmv_dev_csr *m, int lanes, const int *row_list, int n
     }
 }
 
+/* the two instantiated shapes of k_striped: 16 waves over a 128-KiB stripe (one workgroup per CU) and 8 waves over a
+ * 64-KiB stripe (two per CU, which run out of step: one streams while the other stages x or waits at its barrier) */
+template <typename T, int WPB, int XB, int R, bool DIAG>
+void launch_striped(const spmv_dev_striped *t, const void *x, void *y, hipStream_t st, const void *dotv,
+                           void *dot_part, int grid, int nwg, int per, int abl)
+{
+    hipLaunchKernelGGL((k_striped<T, WPB, R, XB, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC, DIAG>), dim3(grid), dim3(WPB * 64), 0,
+                       st, t->tptr, t->rrow, t->wgd, t->col, (const T *)t->val, (const T *)x, (T *)y, (T *)t->partial,
+                       (const T *)dotv, (T *)dot_part, t->rows, t->cols, t->NG, t->GM, t->W, nwg, per, abl);
+}
+
+template <typename T, int WPB, int XB>
+void launch_striped_shape(const spmv_dev_striped *t, const void *x, void *y, hipStream_t st, const void *dotv,
+                                 void *dot_part, int grid, int nwg, int per)
+{
+#ifdef SPMV_HIP_DEBUG_BUILD
+    if (g_tune_abl != 0 || g_tune_tile_k == 3 || g_tune_tile_k == 4) { /* the instrumented twin, on request only */
+        if (g_tune_tile_k == 4)
+            launch_striped<T, WPB, XB, 4, true>(t, x, y, st, dotv, dot_part, grid, nwg, per, g_tune_abl);
+        else if (g_tune_tile_k == 3)
+            launch_striped<T, WPB, XB, 3, true>(t, x, y, st, dotv, dot_part, grid, nwg, per, g_tune_abl);
+        else
+            launch_striped<T, WPB, XB, 2, true>(t, x, y, st, dotv, dot_part, grid, nwg, per, g_tune_abl);
+        return;
+    }
+#endif
+    launch_striped<T, WPB, XB, 2, false>(t, x, y, st, dotv, dot_part, grid, nwg, per, 0);
+}
+
 } // namespace
 
 extern "C" {
@@ -1128,17 +1168,21 @@ void spmvk_set_tuning(int key, int value)
         g_tune_nt = value;
     else if (key == 5 && value >= 0 && value <= 8)
         g_tune_tile_k = value;
+#ifdef SPMV_HIP_DEBUG_BUILD
     else if (key == 6)
         g_tune_abl = value;
+#endif
 }
 
-/* copies the diagnostic stamps of the last k_striped launch with ablation bit 64 (experiments only) */
+#ifdef SPMV_HIP_DEBUG_BUILD
+/* copies the diagnostic stamps of the last k_striped<DIAG> launch with ablation bit 64 (debug build only) */
 int spmvk_striped_stamps(unsigned long long *out, int n)
 {
     if (n > 1024 * 4)
         n = 1024 * 4;
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_striped_stamps), (size_t)n * sizeof(unsigned long long));
 }
+#endif
 
 int spmvk_ordered(const spmv_dev_csr *m, const void *x, void *y, void *stream)
 {
@@ -1247,33 +1291,24 @@ int spmvk_striped(const spmv_dev_striped *t, const void *x, void *y, void *strea
     hipStream_t st = (hipStream_t)stream;
     if (t->rows <= 0)
         return 0;
-    /* the one instantiated shape: 16 waves, 128 KiB of x, 4 entries per lane per sub-window, 16 accumulators */
-    if (t->WPB != SPMV_STRIPE_WPB || t->xbytes != SPMV_STRIPE_XBYTES || t->EPL != SPMV_STRIPE_EPL ||
-        t->wave_rows > SPMV_STRIPE_WAVE_ROWS || (t->NG > 1 && !t->partial))
+    const bool wide = t->WPB == SPMV_STRIPE_WPB && t->xbytes == SPMV_STRIPE_XBYTES;
+    const bool half = t->WPB == SPMV_STRIPE2_WPB && t->xbytes == SPMV_STRIPE2_XBYTES;
+    if ((!wide && !half) || t->EPL != SPMV_STRIPE_EPL || t->wave_rows > SPMV_STRIPE_WAVE_ROWS || (t->NG > 1 && !t->partial))
         return (int)hipErrorInvalidValue;
     const int nwg = t->n_wg;
     const int per = g_tune_xcd ? (nwg + 7) / 8 : 0; /* workgroups of one stripe group share an XCD's L2 for x */
     const int grid = per ? per * 8 : nwg;
-#define SPMV_LS2(T, R)                                                                                          \
-    hipLaunchKernelGGL((k_striped<T, SPMV_STRIPE_WPB, R, SPMV_STRIPE_XBYTES, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC>), \
-                       dim3(grid), dim3(SPMV_STRIPE_WPB * 64), 0, st, t->tptr, t->rrow, t->wgd, t->col,           \
-                       (const T *)t->val, (const T *)x, (T *)y, (T *)t->partial, (const T *)dotv, (T *)dot_part,  \
-                       t->rows, t->cols, t->NG, t->GM, t->W, nwg, per, g_tune_abl)
-#define SPMV_LS2R(T)                                                                                            \
-    do {                                                                                                        \
-        if (g_tune_tile_k == 4)                                                                                 \
-            SPMV_LS2(T, 4);                                                                                     \
-        else if (g_tune_tile_k == 3)                                                                            \
-            SPMV_LS2(T, 3);                                                                                     \
-        else                                                                                                    \
-            SPMV_LS2(T, 2);                                                                                     \
-    } while (0)
-    if (t->elem == 8)
-        SPMV_LS2R(double);
-    else
-        SPMV_LS2R(float);
-#undef SPMV_LS2R
-#undef SPMV_LS2
+    if (t->elem == 8) {
+        if (wide)
+            launch_striped_shape<double, SPMV_STRIPE_WPB, SPMV_STRIPE_XBYTES>(t, x, y, st, dotv, dot_part, grid, nwg, per);
+        else
+            launch_striped_shape<double, SPMV_STRIPE2_WPB, SPMV_STRIPE2_XBYTES>(t, x, y, st, dotv, dot_part, grid, nwg, per);
+    } else {
+        if (wide)
+            launch_striped_shape<float, SPMV_STRIPE_WPB, SPMV_STRIPE_XBYTES>(t, x, y, st, dotv, dot_part, grid, nwg, per);
+        else
+            launch_striped_shape<float, SPMV_STRIPE2_WPB, SPMV_STRIPE2_XBYTES>(t, x, y, st, dotv, dot_part, grid, nwg, per);
+    }
     if (t->NG > 1) {
         const int gs = (t->rows + SPMV_WG - 1) / SPMV_WG;
         if (t->elem == 8)

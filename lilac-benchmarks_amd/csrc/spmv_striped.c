@@ -71,6 +71,13 @@ void spmv_striped_default_opts(spmv_striped_opts *o)
     o->target_wgs = SPMV_STRIPE_TARGET_WGS;
     o->wave_rows = SPMV_STRIPE_WAVE_ROWS;
     o->groups = 0;
+    o->stripes = 0;
+}
+
+int spmv_striped_choose_shape(const spmv_row_stats *st, int elem_size, int cols)
+{
+    (void)st, (void)elem_size, (void)cols;
+    return 1;
 }
 
 /* stripes and stripe groups; the row blocks per group are decided by the builder, from the entries */
@@ -89,6 +96,8 @@ void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped
     wmax -= 16 / elem_size;
     const int unit = 16 / elem_size; /* stripes start on 16-byte boundaries of x */
     int s_min = cols > 0 ? (cols + wmax - 1) / wmax : 1;
+    if (o->stripes > s_min) /* more, narrower stripes than the buffer demands: so that they divide into the groups */
+        s_min = o->stripes;
     /*
      * Stripe groups.  A wave holds at most wave_rows row accumulators, which sets the least number of row
      * blocks; within that, as many stripe groups as keep the workgroups within the target (every workgroup
@@ -374,49 +383,80 @@ static void cut_rows(const uint32_t *wgt, int rows, int n, int wave_rows, int32_
 }
 
 /*
- * How many stripe groups?  S stripes rarely divide into the groups: groups of ceil(S/ng) and of floor(S/ng) stripes
- * get row blocks in proportion to their stripes, never fewer than nb_min (the accumulators), and all blocks together
- * must not outnumber the target (a workgroup that does not fit waits for a whole round).  A workgroup's time is
- * modelled as stripes x (its waves' tile, rounded up to whole sub-windows, + RESTAGE entries for the change of
- * stripe: two barriers and 128 KB of x cost a wave about what 500 entries do); of the group counts from `ng_max`
- * downwards the one with the cheapest most expensive workgroup wins, the larger count on a tie.  Class C: 10 groups
- * of 1 stripe (25-26 row blocks each); a class D row block of 187 500 rows: 20 groups (21 would need 261 workgroups);
- * all of class D: 2 groups of 46 stripes.
+ * How many stripe groups, and how many stripes?  A workgroup's time is modelled as stripes x (its waves' tile, rounded up
+ * to whole sub-windows, + RESTAGE entries for the change of stripe: two barriers and the stripe of x cost a wave about
+ * what 400-500 entries do -- 2.1 us per stripe on a class D row block, profiles/r03_wgtimes.log) plus its share of the
+ * partial sums (written once and read once per group and row); the launch lasts as long as its most expensive workgroup.
+ *
+ * S stripes rarely divide into the groups: groups of ceil(S/ng) and of floor(S/ng) stripes get row blocks in proportion
+ * to their stripes, never fewer than nb_min (the accumulators: a wave carries wave_rows rows at most), and all blocks
+ * together must not outnumber the target (a workgroup that does not fit waits for a whole round).  Round 3 found what
+ * that costs: on a class D row block of 187 500 rows (92 stripes, 20 groups) the 5-stripe groups could have 13-14 row
+ * blocks but the 4-stripe ones were held at 12 by nb_min, so the workgroups of the former streamed 12 % more entries and
+ * ended 14 us after the latter (151.5 against 137.9 us of a 161-us launch).  So besides the fewest stripes that fit the
+ * LDS buffer, every group count is also tried with the next multiple of itself as the number of (slightly narrower)
+ * stripes: 16 groups x 6 stripes x 16 row blocks = 256 equal workgroups for that block.  Of all candidates the one with
+ * the cheapest most expensive workgroup wins, the larger group count on a tie.  Class C: 10 groups of 1 stripe (25-26 row
+ * blocks each); all of class D: 2 groups of 46 stripes.
  */
 #define STRIPE_RESTAGE_ENTRIES 512
-static int choose_groups(int S, int ng_max, int nb_min, int target, int wpb, int64_t nnz, int64_t sub)
+static double geometry_cost(int S, int cand, int nb_min, int target, int wpb, int64_t nnz, int64_t sub, int rows, int elem)
 {
-    int best = ng_max;
-    double best_cost = 1e300;
     const double per_stripe = (double)nnz / (double)S;
-    for (int cand = ng_max; cand >= 1 && cand >= ng_max - 24; --cand) {
-        const int big = (S + cand - 1) / cand, small = S / cand; /* stripes per group */
-        const int n_big = S - small * cand, n_small = cand - n_big;
-        int nb_big = (int)((int64_t)target * big / S), nb_small = (int)((int64_t)target * small / S);
-        nb_big = nb_big < nb_min ? nb_min : nb_big;
-        nb_small = nb_small < nb_min ? nb_min : nb_small;
-        int left = target - (n_big * nb_big + n_small * nb_small);
-        if (left < 0 && cand > 1)
+    const int big = (S + cand - 1) / cand, small = S / cand; /* stripes per group */
+    const int n_big = S - small * cand, n_small = cand - n_big;
+    int nb_big = (int)((int64_t)target * big / S), nb_small = (int)((int64_t)target * small / S);
+    nb_big = nb_big < nb_min ? nb_min : nb_big;
+    nb_small = nb_small < nb_min ? nb_min : nb_small;
+    int left = target - (n_big * nb_big + n_small * nb_small);
+    if (left < 0 && cand > 1)
+        return -1.0;
+    /* what is left of the target: a block more for every group of a kind, the larger groups first */
+    if (n_big > 0 && left >= n_big)
+        ++nb_big, left -= n_big;
+    if (n_small > 0 && left >= n_small)
+        ++nb_small, left -= n_small;
+    double cost = 0.0;
+    for (int kind = 0; kind < 2; ++kind) {
+        const int n = kind ? n_small : n_big, st = kind ? small : big, nb = kind ? nb_small : nb_big;
+        if (n == 0)
             continue;
-        /* what is left of the target: a block more for every group of a kind, the larger groups first */
-        if (n_big > 0 && left >= n_big)
-            ++nb_big, left -= n_big;
-        if (n_small > 0 && left >= n_small)
-            ++nb_small, left -= n_small;
-        double cost = 0.0;
-        for (int kind = 0; kind < 2; ++kind) {
-            const int n = kind ? n_small : n_big, st = kind ? small : big, nb = kind ? nb_small : nb_big;
-            if (n == 0)
-                continue;
-            const double tile = per_stripe / ((double)nb * wpb);
-            const double padded = (double)(((int64_t)tile + sub - 1) / sub * sub);
-            const double c = st * (padded + STRIPE_RESTAGE_ENTRIES);
-            cost = c > cost ? c : cost;
-        }
-        if (cost < best_cost * (1.0 - 1e-9))
-            best_cost = cost, best = cand;
+        const double tile = per_stripe / ((double)nb * wpb);
+        const double padded = (double)(((int64_t)tile + sub - 1) / sub * sub);
+        const double c = st * (padded + STRIPE_RESTAGE_ENTRIES);
+        cost = c > cost ? c : cost;
     }
-    return best;
+    if (cand > 1) /* the partial sums, in entries (elem + 2 bytes each), per wave */
+        cost += (double)cand * rows * 2.0 * elem / (elem + 2.0) / ((double)target * wpb);
+    return cost;
+}
+
+static void choose_geometry(int s_min, int s_cap, int ng_max, int nb_min, int target, int wpb, int64_t nnz, int64_t sub,
+                            int rows, int elem, int fixed_stripes, int *ng_out, int *s_out)
+{
+    int best = ng_max < 1 ? 1 : ng_max, best_s = s_min;
+    double best_cost = 1e300;
+    const int ng_top = target / (nb_min > 0 ? nb_min : 1) > 0 ? target / (nb_min > 0 ? nb_min : 1) : 1;
+    for (int cand = ng_top; cand >= 1 && cand >= ng_top - 32; --cand) {
+        for (int variant = 1; variant >= 0; --variant) { /* on a tie: the stripes that divide into the groups */
+            int S = s_min;
+            if (variant == 1) {
+                if (fixed_stripes)
+                    continue;
+                S = (s_min + cand - 1) / cand * cand;
+                if (S == s_min || S > s_cap)
+                    continue;
+            }
+            if (cand > S)
+                continue;
+            const double cost = geometry_cost(S, cand, nb_min, target, wpb, nnz, sub, rows, elem);
+            if (cost < 0.0)
+                continue;
+            if (cost < best_cost * (1.0 - 1e-9))
+                best_cost = cost, best = cand, best_s = S;
+        }
+    }
+    *ng_out = best, *s_out = best_s;
 }
 
 /*
@@ -434,11 +474,18 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
         opts = &dflt;
     }
     spmv_striped_geometry(rows, cols, elem_size, opts, t);
-    if (opts->groups <= 0 && t->NG > 1 && rows > 0) {
+    if (opts->groups <= 0 && t->S > 1 && rows > 0) {
         const int64_t per_block = (int64_t)opts->wpb * opts->wave_rows;
-        t->NG = choose_groups(t->S, t->NG, (int)((rows + per_block - 1) / per_block), opts->target_wgs < 1 ? 1 : opts->target_wgs,
-                              opts->wpb, (int64_t)rowstr[r1] - rowstr[r0], 64 * (int64_t)t->EPL);
-        t->GM = (t->S + t->NG - 1) / t->NG;
+        int ng = t->NG, ns = t->S;
+        /* a stripe narrower than 1/4 of the buffer is not worth the equal division */
+        const int s_cap = t->S + t->S / 4 > 32768 ? 32768 : t->S + t->S / 4;
+        choose_geometry(t->S, s_cap, t->NG, (int)((rows + per_block - 1) / per_block), opts->target_wgs < 1 ? 1 : opts->target_wgs,
+                        opts->wpb, (int64_t)rowstr[r1] - rowstr[r0], 64 * (int64_t)t->EPL, rows, elem_size,
+                        opts->stripes > 0, &ng, &ns);
+        spmv_striped_opts o2 = *opts;
+        o2.groups = ng;
+        o2.stripes = ns;
+        spmv_striped_geometry(rows, cols, elem_size, &o2, t);
     }
     const int S = t->S, NG = t->NG, GM = t->GM, WPB = t->WPB;
     if (rows <= 0 || opts->wave_rows < 64 || opts->wave_rows % 64 || S > 32768 /* fastdiv_do */ ||

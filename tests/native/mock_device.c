@@ -36,7 +36,7 @@ int spmv_hip_device_count(void)
 
 struct spmv_hip_matrix {
     int elem, rows, cols, plan, relayout;
-    int64_t nnz;
+    int64_t nnz, first;
     int *rowptr; /* 0-based, local */
     int *col;    /* 1-based copies of the block */
     void *val;
@@ -59,6 +59,7 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     m->rows = row_end - row_begin;
     const int64_t first = (int64_t)rowstr[row_begin] - 1;
     m->nnz = (int64_t)rowstr[row_end] - rowstr[row_begin];
+    m->first = first;
     m->rowptr = (int *)malloc(((size_t)m->rows + 1) * sizeof(int));
     for (int r = 0; r <= m->rows; ++r)
         m->rowptr[r] = rowstr[row_begin + r] - rowstr[row_begin];
@@ -76,6 +77,14 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     __atomic_fetch_add(&mock_creates, 1, __ATOMIC_RELAXED);
     __atomic_fetch_add(&mock_relayout_creates, m->plan == SPMV_HIP_PLAN_STRIPED, __ATOMIC_RELAXED);
     return m;
+}
+int mock_value_refreshes;
+int spmv_hip_matrix_refresh_values(spmv_hip_matrix *m, const void *a, const int *colidx)
+{
+    (void)colidx;
+    memcpy(m->val, (const char *)a + m->first * m->elem, (size_t)m->nnz * (size_t)m->elem);
+    __atomic_fetch_add(&mock_value_refreshes, 1, __ATOMIC_RELAXED);
+    return 0;
 }
 void spmv_hip_matrix_destroy(spmv_hip_matrix *m)
 {

@@ -149,11 +149,12 @@ def test_striped_geometries(pkg, backend, oracle, dtype):
             x = rng.standard_normal(int(ci.max())).astype(dtype)
             y_ref = oracle.spmv(a, x, rs, ci, rows)
             absum = oracle.absum(a, x, rs, ci, rows)
-            for groups, wave_rows, wgs in [(0, 1024, 256), (1, 1024, 256), (2, 256, 256), (3, 64, 40), (1000, 1024, 256),
-                                           (4, 64, 2000)]:
+            for groups, wave_rows, wgs, shape in [(0, 1024, 0, 0), (0, 1024, 0, 2), (1, 1024, 256, 1), (2, 256, 256, 1), (3, 64, 40, 2),
+                                                  (1000, 1024, 256, 1), (4, 64, 2000, 1), (2, 128, 700, 2)]:
                 backend.set_tuning(11, groups)
                 backend.set_tuning(12, wave_rows)
                 backend.set_tuning(9, wgs)
+                backend.set_tuning(15, shape)  # 1: 16 waves x 128 KiB of x, 2: 8 waves x 64 KiB (two workgroups per CU)
                 m = backend.matrix(a, rs, ci, rows)
                 try:
                     try:
@@ -161,7 +162,7 @@ def test_striped_geometries(pkg, backend, oracle, dtype):
                     except RuntimeError as e:
                         assert "not representable" in str(e)
                         continue
-                    tag = "%s groups=%d wave_rows=%d wgs=%d" % (name, groups, wave_rows, wgs)
+                    tag = "%s groups=%d wave_rows=%d wgs=%d shape=%d" % (name, groups, wave_rows, wgs, shape)
                     y = m.spmv_host(x)
                     assert_close_rows(y, y_ref, absum, np.diff(rs), dtype, tag)
                     for _ in range(3):
@@ -171,7 +172,8 @@ def test_striped_geometries(pkg, backend, oracle, dtype):
     finally:
         backend.set_tuning(11, 0)
         backend.set_tuning(12, 1024)
-        backend.set_tuning(9, 256)
+        backend.set_tuning(9, 0)
+        backend.set_tuning(15, 0)
 
 
 def test_timed_call_traffic_and_pinned_memory(pkg, backend, oracle):
@@ -1026,35 +1028,69 @@ def test_bench_line_has_the_contract_keys():
     assert d["npb_cg"]["verified"] and d["npb_cg_device"]["verified"]
 
 
-def test_no_room_for_the_second_copy_is_not_fatal(pkg, backend, oracle):
+def test_no_room_for_the_second_copy_is_not_fatal(pkg):
     """The re-laid-out copy of a matrix (STRIPED, TILED) is an optimisation next to the CSR copy: when the device has
     no memory for it, an automatic choice falls back to the CSR kernels and the product is still right; only asking
-    for the plan by name fails.  (The out-of-memory answer is injected with tuning key 14.)"""
-    rs, ci, a = matgen.npb_like(61, 40000, 200)
+    for the plan by name fails.  The out-of-memory answer is injected with tuning key 14, which only the DEBUG build of
+    the library has (include/spmv_hip_debug.h): a fresh process loads libhip-spmv-debug.so."""
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, pkgload, matgen
+from oracle.oracle import Oracle
+pkg = pkgload.load_package(); be = pkg.Backend(pkg.lib_path("libhip-spmv-debug.so")); orc = Oracle()
+rs, ci, a = matgen.npb_like(61, 40000, 200)
+rows = rs.size - 1
+x = np.random.default_rng(61).standard_normal(rows)
+y_ref = orc.spmv(a, x, rs, ci, rows); absum = orc.absum(a, x, rs, ci, rows)
+tol = (np.diff(rs) + 24.0) * 2.0 ** -53 * absum
+m = be.matrix(a, rs, ci, rows)
+assert m.info()["plan"] == pkg.PLAN_STRIPED  # what AUTO picks for this shape when there is room
+m.close()
+be.set_tuning(14, 1)
+m = be.matrix(a, rs, ci, rows)
+assert m.info()["plan"] == pkg.PLAN_STREAM
+assert np.all(np.abs(m.spmv_host(x) - y_ref) <= tol), "fallback at creation"
+be.set_tuning(14, 1)
+try:
+    m.set_plan(pkg.PLAN_STRIPED, 0)
+    raise SystemExit("asking for the plan by name must fail")
+except RuntimeError as e:
+    assert "out of memory" in str(e) or "upload failed" in str(e), e
+be.set_tuning(14, 1)
+m.set_plan(pkg.PLAN_AUTO, 0)  # the automatic choice again: still no room, still served
+assert m.info()["plan"] == pkg.PLAN_STREAM
+m.set_plan(pkg.PLAN_AUTO, 0)  # and with room the layout is built after all
+assert m.info()["plan"] == pkg.PLAN_STRIPED
+assert np.all(np.abs(m.spmv_host(x) - y_ref) <= tol), "striped after the fallback"
+m.close()
+print("oom-ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "oom-ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_the_shipped_library_has_no_diagnostics(pkg, backend):
+    """ablation switches, clock stamps and fault injection live in the debug build only.  The shipped
+    library does not export the stamp reader, and its tuning keys 6 / 14 are inert (a product under "ablation" is right)."""
+    import ctypes
+    assert not hasattr(ctypes.CDLL(pkg.lib_path()), "spmv_hip_debug_stamps")
+    rs, ci, a = matgen.npb_like(62, 30000, 200)
     rows = rs.size - 1
-    x = np.random.default_rng(61).standard_normal(rows)
-    y_ref = oracle.spmv(a, x, rs, ci, rows)
-    absum = oracle.absum(a, x, rs, ci, rows)
+    x = np.random.default_rng(62).standard_normal(rows)
     m = backend.matrix(a, rs, ci, rows)
     try:
-        assert m.info()["plan"] == pkg.PLAN_STRIPED  # what AUTO picks for this shape when there is room
-    finally:
-        m.close()
-    backend.set_tuning(14, 1)
-    m = backend.matrix(a, rs, ci, rows)
-    try:
-        assert m.info()["plan"] == pkg.PLAN_STREAM
-        assert_close_rows(m.spmv_host(x), y_ref, absum, np.diff(rs), np.float64, "fallback at creation")
+        m.set_plan(pkg.PLAN_STRIPED, 0)
+        y0 = m.spmv_host(x)
+        backend.set_tuning(6, 4 | 8 | 16)  # in the debug build: no accumulators, no ring, no scan -- wrong results
         backend.set_tuning(14, 1)
-        with pytest.raises(RuntimeError, match="out of memory|upload failed"):
-            m.set_plan(pkg.PLAN_STRIPED, 0)
-        backend.set_tuning(14, 1)
-        m.set_plan(pkg.PLAN_AUTO, 0)  # the automatic choice again: still no room, still served
-        assert m.info()["plan"] == pkg.PLAN_STREAM
-        m.set_plan(pkg.PLAN_AUTO, 0)  # and with room the layout is built after all
-        assert m.info()["plan"] == pkg.PLAN_STRIPED
-        assert_close_rows(m.spmv_host(x), y_ref, absum, np.diff(rs), np.float64, "striped after the fallback")
+        y1 = m.spmv_host(x)
+        assert np.array_equal(bits(y0), bits(y1))
+        m2 = backend.matrix(a, rs, ci, rows)
+        assert m2.info()["plan"] == pkg.PLAN_STRIPED  # no injected out-of-memory either
+        m2.close()
     finally:
+        backend.set_tuning(6, 0)
         backend.set_tuning(14, 0)
         m.close()
 

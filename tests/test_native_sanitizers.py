@@ -46,7 +46,7 @@ def test_abi_harness_on_a_mock_device(tmp_path, san):
         pytest.skip("no gcc")
     exe = str(tmp_path / "harness_driver")
     flags = ["-fsanitize=" + san] if san else []
-    cc = subprocess.run(["gcc", "-std=gnu11", "-O1", "-g", "-fno-omit-frame-pointer"] + flags +
+    cc = subprocess.run(["gcc", "-std=gnu11", "-O1", "-g", "-fno-omit-frame-pointer", "-DSPMV_TESTING"] + flags +
                         ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + HARNESS_SOURCES +
                         ["-lm", "-lpthread", "-ldl", "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if cc.returncode != 0 and san and "sanitize" in cc.stdout:

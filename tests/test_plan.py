@@ -238,14 +238,14 @@ class StripedHost(ctypes.Structure):
 
 class StripedOpts(ctypes.Structure):
     _fields_ = [("xbytes", ctypes.c_int), ("wpb", ctypes.c_int), ("target_wgs", ctypes.c_int),
-                ("wave_rows", ctypes.c_int), ("groups", ctypes.c_int)]
+                ("wave_rows", ctypes.c_int), ("groups", ctypes.c_int), ("stripes", ctypes.c_int)]
 
 
 def striped_build(lib, rs, ci, a, xbytes=65536, wpb=8, wgs=6, wave_rows=128, groups=0):
     rows = rs.size - 1
     cols = int(ci.max()) if ci.size else 0
     t = StripedHost()
-    o = StripedOpts(xbytes, wpb, wgs, wave_rows, groups)
+    o = StripedOpts(xbytes, wpb, wgs, wave_rows, groups, 0)
     lib.spmv_striped_build.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.POINTER(StripedOpts), ctypes.POINTER(StripedHost)]
     rc = lib.spmv_striped_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, rows, cols, a.dtype.itemsize,
@@ -441,3 +441,26 @@ def test_striped_groups_balance_their_workgroups(lib):
     per_wg = per_wave.max(axis=1)
     assert per_wg.max() <= 1.12 * per_wg.mean(), (per_wg.max(), per_wg.mean())
     assert 36 <= geo["n_wg"] <= 40
+
+
+def test_striped_geometry_prefers_stripes_that_divide_into_the_groups(lib):
+    """The class D row block of round 3 in small: the fewest stripes that fit the buffer (23) do not divide into any
+    admissible group count, the accumulators (wave_rows) hold the smaller groups at a minimum of row blocks, and the
+    workgroups of the larger groups would stream a good deal more than the others.  The builder then takes a few more,
+    slightly narrower stripes (24 = 8 groups x 3) so that all workgroups are alike."""
+    rng = np.random.default_rng(11)
+    rows, cols = 6144, 8190 * 23 - 500
+    rs, ci, a = matgen.random_csr(11, rows, cols, 400, spread=0.2)
+    x = rng.standard_normal(int(ci.max()))
+    rc, res = striped_emulate(lib, rs, ci, a, x, xbytes=65536, wpb=8, wgs=40, wave_rows=256, groups=0)
+    assert rc == 0
+    y, geo = res
+    assert geo["S"] > 23 and geo["S"] % geo["NG"] == 0, geo  # equal groups
+    assert 36 <= geo["n_wg"] <= 40
+    per_wave = geo["tiles"].sum(axis=1).reshape(geo["n_wg"], geo["WPB"])
+    per_wg = per_wave.sum(axis=1)
+    assert per_wg.max() <= 1.04 * per_wg.mean(), (per_wg.max(), per_wg.mean())
+    # and the product is the product
+    prod = a * x[ci - 1]
+    want = np.add.reduceat(prod, rs[:-1] - 1)
+    assert np.allclose(y, want, rtol=1e-12, atol=1e-12)

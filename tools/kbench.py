@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--xbytes", type=int, default=32768, help="bytes of x per LDS stripe of the TILED kernel")
     ap.add_argument("--blocks", type=int, default=0, help="TILED workgroups aimed for (0 = default 512)")
     ap.add_argument("--tk", type=int, default=0, help="TILED: 256-entry sub-windows per register window")
-    ap.add_argument("--swgs", type=int, default=256, help="STRIPED: workgroups aimed for")
+    ap.add_argument("--swgs", type=int, default=0, help="STRIPED: workgroups aimed for (0 = the shape's default: 256 / 512)")
+    ap.add_argument("--sshape", default="0", help="STRIPED: comma list of kernel shapes to time: 0 = chosen per matrix, 1 = 16 waves x 128 KiB, 2 = 8 waves x 64 KiB (two workgroups per CU)")
     ap.add_argument("--sgroups", default="0", help="STRIPED: comma list of stripe-group counts to time (0 = the builder's choice); "
                                                    "each value builds the layout anew")
     ap.add_argument("--swrows", type=int, default=1024, help="STRIPED: most rows per wave range (multiple of 64, <= 1024)")
@@ -70,7 +71,12 @@ def main():
     ap.add_argument("--plans", default="", help="comma list of plan names to run (default all)")
     args = ap.parse_args()
     pkg = pkgload.load_package()
-    be = pkg.Backend()
+    # ablation masks and clock stamps exist in the debug build only (include/spmv_hip_debug.h); plain timings use the
+    # shipped library
+    diag = args.stamps or args.ab_rounds > 0 or any(int(v) for v in args.abl.split(","))
+    be = pkg.Backend(pkg.lib_path("libhip-spmv-debug.so")) if diag else pkg.Backend()
+    if diag:
+        print("# debug library: %s" % be.path)
     assert be.device_count() >= 1
     be.set_tuning(2, args.wpb)
     be.set_tuning(3, args.xbytes)
