@@ -10,28 +10,38 @@ and y already resident in HBM.
   N = 1   workload = BASELINE.json configs[1]: the NPB3.3.1 CG class C matrix (150000 rows,
           36121058 nonzeros), generated in-process by our restatement of makea.
   N > 1   workload = BASELINE.json configs[4]: the NPB CG class D matrix (1500000 rows,
-          ~694.4 M nonzeros) row-partitioned over the N ranks (one process per GPU, block rows
-          of about equal nnz, x replicated on every GPU, NO collective on the data path).  Each rank
-          generates only its own row block.  torch.distributed is used for the barrier and
-          the max-over-ranks of the elapsed time, nothing else.  Two figures per step: `value` =
-          the kernels alone on HBM-resident x / y (the contract's figure), and `gather_inclusive` =
-          what libspmv/gpu.c:264,285 do around them on every call: x from ONE pinned host vector
-          (shared memory, written by rank 0 as the caller would) to every GPU over its own PCIe
-          link, and each rank's slice of y copied straight to its row offset of ONE shared host
-          vector (the host gather).
+          ~694.4 M nonzeros) row-partitioned over N GPUs (block rows of about equal nnz, x replicated
+          on every GPU, NO collective on the data path).  Two ways to get there:
+            * under a launcher (WORLD_SIZE = N: one process per GPU, what the driver starts): each rank
+              generates only its own row block; torch.distributed is used for the barrier and the
+              max-over-ranks of the elapsed time, nothing else;
+            * WITHOUT a launcher (`python bench.py --gpus N`): ONE process drives the N GPUs through the
+              library's own multi-device paths -- one device-resident row block per GPU for the kernel
+              figure (spmv_hip_time_multi), SPMV_HIP_DEVICES=N behind spmv_harness_ for everything that
+              goes through the ABI.  With fewer than N GPUs visible the row blocks wrap around the
+              visible ones (a rehearsal: the line says so in `devices_used`).
+          Either way the line carries, besides `value` (kernels alone, x / y resident in HBM: the
+          contract's figure), `gather_inclusive` (what libspmv/gpu.c:264,285 do around the kernels on
+          every call: x host -> every GPU, y slices back: the host gather) and `npb_cg`: the complete
+          NPB CG class D benchmark through spmv_harness_ from ONE process with SPMV_HIP_DEVICES=N
+          (the call pattern of NPB3.3.1/CG/cg.f:532,628), MOp/s by cg.f:395-402, verified against
+          cg.f:122-163.
 
 value = 2 * nnz * K / elapsed  (effective GFLOP/s, whole job).  The same K launches are
 bracketed by HIP events recorded on the stream the kernels run on (spmv_hip_time_device), which
 gives the per-launch duration for the roofline object.  Rank 0 at N = 1 additionally reports
-  * npb_cg: the complete NPB CG class C benchmark through the drop-in ABI (host vectors, PCIe
-    round trip of x and y on each of its 1976 SpMV calls) -> MOp/s by cg.f:395-402, verified
-    against cg.f:122-163;
+  * cold: the first 20 launches after the upload, before anything has settled;
+  * npb_cg / npb_cg_device: the complete NPB CG class C benchmark through the drop-in ABI (host vectors,
+    PCIe round trip of x and y on each of its 1976 SpMV calls) and through the opt-in device-resident CG;
+  * sparsebench_170, graphs_rmat20, parboil: BASELINE configs[2] and [3] on the same library, each
+    checked against numpy / the oracle outside its timed region;
   * scale_ref: class D (the N > 1 workload) on this one GPU, the like-for-like first point of the
     strong-scaling series;
   * cpu_baseline: the reference's CPU path (oracle/_ref/native.so when it was built in the
     authoring container, else our port) on one host core, on a bounded sample.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -43,6 +53,7 @@ if ROOT not in sys.path:
 
 MEASURED_READ_CEILING_GBS = 6386.6
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+ZETA_D = 52.514532105794  # cg.f:122-163
 
 
 def cpu_model():
@@ -59,6 +70,167 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def tolerance(np, lens, absum, eps=2.0 ** -53):
+    """the per-row bar of tests/test_gpu_parity.py (assert_close_rows), derived per plan in tests/rowtol.py"""
+    from rowtol import row_tolerance
+    return row_tolerance(lens, absum, eps)
+
+
+def check_rows(np, m_a, m_rowstr, m_colidx, x, yv, what):
+    """EVERY row of a result against numpy (segment sums of a * x[col]), within the any-order summation bound"""
+    prod = m_a * x[m_colidx - 1]
+    starts = (m_rowstr[:-1] - m_rowstr[0]).astype(np.int64)
+    lens = np.diff(m_rowstr)
+    nz = lens > 0
+    want = np.zeros(lens.size)
+    scale = np.zeros(lens.size)
+    if prod.size:
+        want[nz] = np.add.reduceat(prod, starts[nz])
+        scale[nz] = np.add.reduceat(np.abs(prod), starts[nz])
+    badrows = np.nonzero(~(np.abs(yv - want) <= tolerance(np, lens, scale) + 1e-300))[0]
+    assert badrows.size == 0, "%s: %d rows differ, first %d: %r vs %r" % (what, badrows.size, badrows[0], yv[badrows[0]], want[badrows[0]])
+
+
+def npb_cg_object(m, be, res, st, runs, cls, path):
+    return {
+        "class": cls, "mops": round(res["mops"], 2), "time_s": round(res["t_bench"], 4),
+        "repeats": len(runs), "mops_all": [round(r["mops"], 1) for r in runs],
+        "verified_all": all(bool(r["verified"]) for r in runs),
+        "time_in_spmv_s": round(res["t_spmv"], 4), "spmv_calls": res["spmv_calls"],
+        "zeta": res["zeta"], "err": res["err"], "verified": bool(res["verified"]),
+        "path": path,
+        "upload_s": round(st["t_upload"], 4), "init_s": round(st["t_init"], 4),
+        # SURVEY 8(d) "also report": the PCIe-inclusive time of one ABI call (entry -> return: x H2D, kernels, y D2H)
+        "us_per_abi_call": round(res["t_spmv"] / max(1, res["spmv_calls"]) * 1e6, 2),
+        "one_time": "init_s (HIP context + code object, first call of the process) and upload_s (matrix H2D + re-layout, "
+                    "inside the untimed first conj_grad, cg.f:233) are not part of time_s",
+    }
+
+
+def npb_through_the_abi(pkg, be, cls, n_dev, repeats, np):
+    """The complete NPB CG benchmark through spmv_harness_ from THIS process, the matrix row-partitioned over n_dev GPUs by
+    the library itself (SPMV_HIP_DEVICES, read at the first device product of the ABI): what cg.f:532,628 would get."""
+    visible = be.device_count()
+    if n_dev > 1:
+        os.environ["SPMV_HIP_DEVICES"] = str(min(n_dev, visible))
+        os.environ["SPMV_HIP_PARTS"] = str(n_dev)
+    t0 = time.time()
+    m = pkg.npb.NpbMatrix(cls)
+    t_gen = time.time() - t0
+    be.reset_stats()
+    runs = [m.run_cg(be.harness_fn()) for _ in range(max(1, repeats))]
+    st = be.stats()
+    res = sorted(runs, key=lambda r: r["mops"])[len(runs) // 2]  # median run (reference convention: 5 repeats)
+    inf = be.abi_matrix_info()
+    obj = npb_cg_object(m, be, res, st, runs, cls,
+                        "spmv_harness_ ABI: host x/y every call (PCIe round trip), host vector loops on 1 core" +
+                        ("; one process, SPMV_HIP_DEVICES=%d SPMV_HIP_PARTS=%d: x to every GPU, y slices gathered on the host, no collective"
+                         % (min(n_dev, visible), n_dev) if n_dev > 1 else ""))
+    obj["generated_s"] = round(t_gen, 1)
+    obj["uploads"] = int(st["uploads"])
+    obj["plan"] = pkg.abi.PLAN_NAMES[inf["plan"]] if inf else None
+    if n_dev > 1:
+        obj["devices_used"], obj["row_partitions"] = min(n_dev, visible), n_dev
+    be.release()
+    return obj, m
+
+
+def other_configs(pkg, be, np, line):
+    """BASELINE configs[2] and [3] on the library the headline ran on: SparseBench 170^3 (unsymmetric, BiCG call pattern),
+    R-MAT scale 20 (bfs / pagerank call patterns), parboil's two bundled datasets (float ABI, 50 products).  Each checked
+    outside its timed region."""
+    C = pkg.callers
+    # ---- SparseBench 170^3: kernel (HBM-resident) and the ABI call (78 MB of x + y across PCIe)
+    t0 = time.time()
+    sb = C.sb_generate(170)
+    rs, ci, a = sb.arrays()
+    dm = be.matrix(a, rs, ci, sb.rows)
+    inf = dm.info()
+    x = np.random.default_rng(170).standard_normal(inf["cols"] + 2)
+    dx, dy = be.malloc(x.nbytes), be.malloc(sb.rows * 8 + 16)
+    be.h2d(dx, x)
+    dm.time_device(dx, dy, 5)
+    ms = dm.time_device(dx, dy, 20) / 20
+    y = be.d2h(np.empty(sb.rows), dy)
+    check_rows(np, a, rs, ci, x, y, "sparsebench 170 kernel")
+    dm.close(), be.free(dx), be.free(dy)
+    be.reset_stats()
+    yy = np.empty(sb.rows)
+    be.harness(yy, a, x, rs, ci, sb.rows)  # upload
+    t1 = time.perf_counter()
+    for _ in range(10):
+        be.harness(yy, a, x, rs, ci, sb.rows)
+    abi_ms = (time.perf_counter() - t1) / 10 * 1e3
+    check_rows(np, a, rs, ci, x, yy, "sparsebench 170 through the ABI")
+    be.release()
+    line["sparsebench_170"] = {
+        "rows": sb.rows, "nnz": int(sb.nnz), "plan": pkg.abi.PLAN_NAMES[inf["plan"]], "kernel_us": round(ms * 1e3, 2),
+        "frac": round(inf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "algorithmic_bytes_per_launch": inf["algorithmic_bytes"], "abi_ms_per_call": round(abi_ms, 3),
+        "abi_moves": "x and y, 39 MB each, host <-> GPU on every call (random.f:32,72)", "setup_s": round(time.time() - t0, 1),
+    }
+    C.free(sb)
+    # ---- graphs: R-MAT 2^20, edge factor 16: bfs (16 sources, values 1) and pagerank (column-normalised x 0.85)
+    t0 = time.time()
+    g = C.graph_rmat(20, 16)
+    rs, ci, a = g.arrays()
+    be.reset_stats()
+    t1 = time.perf_counter()
+    levels = 0
+    sources = np.nonzero(np.diff(rs) >= 8)[0][:: max(1, g.rows // 64)][:16]  # 16 vertices that have somewhere to go
+    for src in sources:
+        lv, dist = C.bfs_run(g, be.harness_fn(), int(src))
+        levels += lv
+    bfs_s = time.perf_counter() - t1
+    st = be.stats()
+    be.release()
+    dm = be.matrix(a, rs, ci, g.rows)
+    inf = dm.info()
+    x = np.random.default_rng(20).standard_normal(inf["cols"] + 2)
+    dx, dy = be.malloc(x.nbytes), be.malloc(g.rows * 8 + 16)
+    be.h2d(dx, x)
+    dm.time_device(dx, dy, 5)
+    ms = dm.time_device(dx, dy, 20) / 20
+    check_rows(np, a, rs, ci, x, be.d2h(np.empty(g.rows), dy), "rmat 20 kernel")
+    dm.close(), be.free(dx), be.free(dy)
+    iters = 20
+    t1 = time.perf_counter()
+    pr, err = C.pagerank(g, be.harness_fn(), iters)
+    pr_ms = (time.perf_counter() - t1) / iters * 1e3
+    assert np.all(np.isfinite(pr)) and np.all(pr >= 0.0) and 0.0 < float(pr.sum()) <= 1.0 + 1e-9  # dangling vertices leak rank (main.cpp:128-149 does not redistribute it)
+    be.release()
+    line["graphs_rmat20"] = {
+        "rows": g.rows, "nnz": int(g.nnz), "plan": pkg.abi.PLAN_NAMES[inf["plan"]], "spmv_us": round(ms * 1e3, 2),
+        "frac": round(inf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "bfs_s": round(bfs_s, 4), "bfs_sources": int(len(sources)), "bfs_spmv_calls": int(levels), "bfs_uploads": int(st["uploads"]),
+        "pagerank_ms_per_iter": round(pr_ms, 3), "pagerank_iters": iters, "setup_s": round(time.time() - t0, 1),
+        "what": "bfs/bfs.cc:36-68 and pagerank/main.cpp:128-149 call patterns through spmv_harness_ (first call uploads); "
+                "frontiers are bit-exact by construction (integer-valued products), checked in tests/test_gpu_parity.py",
+    }
+    C.free(g)
+    # ---- parboil: the two bundled datasets, 50 products each through f_spmv_harness_ under the default dispatch
+    pb = {}
+    for name, mtx in (("small", "1138_bus.mtx"), ("medium", "bcsstk18.mtx")):
+        d = os.path.join(ROOT, "tests", "golden", "parboil_" + name)
+        if not os.path.exists(os.path.join(d, mtx)):
+            continue
+        m = C.pb_load(os.path.join(d, mtx))
+        be.reset_stats()
+        t1 = time.perf_counter()
+        yv = C.pb_run(m, be.harness_fn(np.float32), os.path.join(d, "vector.bin"), 50)
+        pb[name + "_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+        st = be.stats()
+        pb[name + "_dispatched_to"] = "host loop" if st["host_calls"] == st["calls"] else ("device" if st["host_calls"] == 0 else "both")
+        assert np.all(np.isfinite(yv))
+        be.release()
+        C.free(m)
+    if pb:
+        pb["what"] = "parboil/benchmarks/spmv/src/cpu/main.c:93-95: 50 x f_spmv_harness_, file reading excluded; outputs pass the " \
+                     "reference's comparator in tests/test_gpu_parity.py"
+        pb["dispatch"] = os.environ.get("SPMV_HIP_DISPATCH", "auto")
+        line["parboil"] = pb
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,22 +239,26 @@ def main():
     ap.add_argument("--cls", default=None, help="override the NPB class (default: C at N=1, D at N>1)")
     ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered|tiled|striped")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-npb", action="store_true", help="skip the full NPB CG run through the ABI")
+    ap.add_argument("--no-npb", action="store_true", help="skip the full NPB CG runs through the ABI")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sparsebench / graphs / parboil objects (N = 1)")
     ap.add_argument("--cpu-iters", type=int, default=10, help="timed CG iterations of the CPU sample")
     ap.add_argument("--no-scale-ref", action="store_true", help="skip the class D single-GPU reference point at N=1")
-    ap.add_argument("--npb-repeats", type=int, default=5, help="runs of the full NPB CG benchmark; the median is reported")
+    ap.add_argument("--npb-repeats", type=int, default=5, help="runs of the full NPB CG benchmark at N=1; the median is reported")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import pkgload
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    # no launcher: ONE process drives --gpus N GPUs through the library's own multi-device paths (never a silent N = 1)
+    inproc = world == 1 and args.gpus > 1
+    if world > 1 and world != args.gpus:
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
-    n_gpus = world
+    n_gpus = args.gpus if inproc else world
     dist = None
     # rehearsal aid: BENCH_DIST_BACKEND=gloo lets several ranks share the one GPU of a test box
     # (RCCL refuses two ranks on one device); the driver's real runs use nccl = RCCL, one GPU per rank
@@ -105,28 +281,7 @@ def main():
     device = (local_rank % max(ndev, 1)) if world > 1 else 0
     torch.cuda.set_device(device)
     red_dev = "cuda" if backend_name == "nccl" else "cpu"
-
     cls = args.cls or ("C" if n_gpus == 1 else "D")
-    t0 = time.time()
-    if n_gpus == 1:
-        m = pkg.npb.NpbMatrix(cls)
-    else:
-        m = pkg.npb.NpbMatrix(cls, part=rank, nparts=n_gpus)
-    log("[rank %d] class %s rows [%d,%d) nnz=%d generated in %.1f s" % (
-        rank, cls, m.row_begin, m.row_end, m.nnz, time.time() - t0))
-
-    # device-resident block, replicated x, local y
-    dm = be.matrix(m.a, m.rowstr, m.colidx, m.rows, device=device, cols_hint=m.na)
-    if args.plan != "auto":
-        name, _, par = args.plan.partition(":")
-        plan = {"stream": pkg.PLAN_STREAM, "vector": pkg.PLAN_VECTOR, "binned": pkg.PLAN_BINNED,
-                "ordered": pkg.PLAN_ORDERED, "tiled": pkg.PLAN_TILED, "striped": pkg.PLAN_STRIPED}[name]
-        dm.set_plan(plan, int(par) if par else 0)
-    info = dm.info()
-    x = np.random.default_rng(12345).standard_normal(m.na + 2)  # same on every rank: x is replicated
-    dx = be.malloc(x.nbytes, device)
-    dy = be.malloc(max(m.rows, 1) * 8, device)
-    be.h2d(dx, x, device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -134,112 +289,166 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: a fixed pre-warm (the first dozen passes over a freshly uploaded layout run 5-10 % slower, class D most:
-    # profiles/r02_kbench_npb_shapes_steady_state.log), then the W warm-up steps asked for; the line reports both
-    PREWARM = 0
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.05 or PREWARM < 12:  # ~50 ms of back-to-back products: clocks and caches settled
-        dm.time_device(dx, dy, 12)
-        PREWARM += 12
-    for _ in range(args.warmup):
-        dm.spmv_device(dx, dy)
-    be.synchronize(device)
-    barrier()
-    t_start = time.perf_counter()
-    ev_ms = dm.time_device(dx, dy, args.steps)  # K launches, HIP events on the launch stream, synchronised
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    barrier()
-
-    nnz_total = float(m.nnz)
-    rank_ms = None
-    if dist is not None:
-        mine = torch.zeros(n_gpus, dtype=torch.float64, device=red_dev)
-        mine[rank] = elapsed * 1e3 / args.steps
-        dist.all_reduce(mine, op=dist.ReduceOp.SUM)  # every rank's own ms per step, for the balance of the partition
-        rank_ms = [round(float(v), 6) for v in mine.tolist()]
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([float(m.nnz)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        nnz_total = float(s.item())
-
-    # the timed kernel really computed y = A*x: EVERY local row against numpy (segment sums of a * x[col]), within the
-    # any-order summation bound; outside the timed region
-    y = np.empty(m.rows)
-    be.d2h(y, dy, device)
-
-    def check_rows(yv, what):
-        prod = m.a * x[m.colidx - 1]
-        starts = (m.rowstr[:-1] - m.rowstr[0]).astype(np.int64)
-        want = np.add.reduceat(prod, starts)
-        scale = np.add.reduceat(np.abs(prod), starts)
-        lens = np.diff(m.rowstr)
-        want[lens == 0] = 0.0
-        scale[lens == 0] = 0.0
-        badrows = np.nonzero(~(np.abs(yv - want) <= (lens + 24.0) * 2.0 ** -53 * scale + 1e-300))[0]
-        assert badrows.size == 0, "%s: %d rows differ, first %d: %r vs %r" % (what, badrows.size, badrows[0],
-                                                                            yv[badrows[0]], want[badrows[0]])
-
-    check_rows(y, "kernel")
-
-    # N > 1: the same step with the traffic of an ABI call around the kernels (libspmv/gpu.c:264,285)
+    # =============================================================== the kernel figure
+    t0 = time.time()
+    cold = None
     gather = None
-    if dist is not None:
-        from lilac_benchmarks_amd.hostgather import SharedVector
-        tag = "hipspmv_bench_%s" % os.environ.get("MASTER_PORT", "0")
-        if rank == 0:
-            xs = SharedVector(tag + "_x", m.na + 2, create=True)
-            xs.arr[:] = x
-            xs.arr.flush()
-            SharedVector(tag + "_y", m.na, create=True).close()
-        barrier()
-        if rank != 0:
-            xs = SharedVector(tag + "_x", m.na + 2)
-        ys = SharedVector(tag + "_y", m.na)
-        pinned_x = be.host_register(xs.arr)
-        pinned_y = be.host_register(ys.arr)
-        y_slice = ys.arr[m.row_begin:m.row_end]
-        dm.time_call(xs.arr, y_slice, dx, dy, max(1, args.warmup))
+    rank_ms = None
+    devices_used = None
+    if inproc:
+        # ---- one process, N device-resident row blocks (wrapping onto the visible GPUs when there are fewer)
+        visible = be.device_count()
+        devices_used = min(n_gpus, visible)
+        parts = [pkg.npb.NpbMatrix(cls, part=p, nparts=n_gpus) for p in range(n_gpus)]
+        log("class %s in %d row blocks generated in %.1f s" % (cls, n_gpus, time.time() - t0))
+        m = parts[0]
+        x = np.random.default_rng(12345).standard_normal(m.na + 2)
+        dms, dxs, dys = [], [], []
+        for p, mp in enumerate(parts):
+            d = p % visible
+            dms.append(be.matrix(mp.a, mp.rowstr, mp.colidx, mp.rows, device=d, cols_hint=mp.na))
+            dxs.append(be.malloc(x.nbytes, d))
+            dys.append(be.malloc(max(mp.rows, 1) * 8, d))
+            be.h2d(dxs[-1], x, d)
+        info = dms[0].info()
+        infos = [dm.info() for dm in dms]
+        PREWARM = 0
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.05 or PREWARM < 12:
+            be.time_multi(dms, dxs, dys, 12)
+            PREWARM += 12
+        be.time_multi(dms, dxs, dys, max(1, args.warmup))
+        t_start = time.perf_counter()
+        ev_each = be.time_multi(dms, dxs, dys, args.steps)  # K launches per block, rep by rep; HIP events on every block's stream
+        elapsed = time.perf_counter() - t_start
+        ev_ms = max(ev_each)
+        rank_ms = [round(v / args.steps, 6) for v in ev_each]
+        nnz_total = float(sum(mp.nnz for mp in parts))
+        for p, mp in enumerate(parts):
+            y = be.d2h(np.empty(mp.rows), dys[p], p % visible)
+            check_rows(np, mp.a, mp.rowstr, mp.colidx, x, y, "kernel, row block %d" % p)
+        alg_bytes_rank0 = info["algorithmic_bytes"]
+        for p in range(n_gpus):
+            dms[p].close()
+            be.free(dxs[p], p % visible)
+            be.free(dys[p], p % visible)
+        for mp in parts:
+            mp.close()
+        m_na, m_rows_total = m.na, sum(i["rows"] for i in infos)
+    else:
+        if n_gpus == 1:
+            m = pkg.npb.NpbMatrix(cls)
+        else:
+            m = pkg.npb.NpbMatrix(cls, part=rank, nparts=n_gpus)
+        log("[rank %d] class %s rows [%d,%d) nnz=%d generated in %.1f s" % (
+            rank, cls, m.row_begin, m.row_end, m.nnz, time.time() - t0))
+        # device-resident block, replicated x, local y
+        dm = be.matrix(m.a, m.rowstr, m.colidx, m.rows, device=device, cols_hint=m.na)
+        if args.plan != "auto":
+            name, _, par = args.plan.partition(":")
+            plan = {"stream": pkg.PLAN_STREAM, "vector": pkg.PLAN_VECTOR, "binned": pkg.PLAN_BINNED,
+                    "ordered": pkg.PLAN_ORDERED, "tiled": pkg.PLAN_TILED, "striped": pkg.PLAN_STRIPED}[name]
+            dm.set_plan(plan, int(par) if par else 0)
+        info = dm.info()
+        x = np.random.default_rng(12345).standard_normal(m.na + 2)  # same on every rank: x is replicated
+        dx = be.malloc(x.nbytes, device)
+        dy = be.malloc(max(m.rows, 1) * 8, device)
+        be.h2d(dx, x, device)
+        # cold: the first 20 launches after the upload, before clocks, TLBs and caches have seen the layout
+        cold_ms = dm.time_device(dx, dy, 20) / 20
+        cold = {"launch_us": round(cold_ms * 1e3, 3), "launches": 20,
+                "achieved": round(info["algorithmic_bytes"] / (cold_ms * 1e-3) / 1e9, 2),
+                "frac": round(info["algorithmic_bytes"] / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "what": "the first 20 launches after the upload of the matrix, nothing run before them (DESIGN.md 4.4: "
+                        "the first launches over a fresh layout run slower)"}
+        # untimed: a fixed pre-warm, then the W warm-up steps asked for; the line reports both
+        PREWARM = 20
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.05 or PREWARM < 32:  # ~50 ms of back-to-back products
+            dm.time_device(dx, dy, 12)
+            PREWARM += 12
+        for _ in range(args.warmup):
+            dm.spmv_device(dx, dy)
+        be.synchronize(device)
         barrier()
         t_start = time.perf_counter()
-        ev_ms_g = dm.time_call(xs.arr, y_slice, dx, dy, args.steps)
+        ev_ms = dm.time_device(dx, dy, args.steps)  # K launches, HIP events on the launch stream, synchronised
         torch.cuda.synchronize()
-        el_g = time.perf_counter() - t_start
+        elapsed = time.perf_counter() - t_start
         barrier()
-        mine = torch.zeros(n_gpus, dtype=torch.float64, device=red_dev)
-        mine[rank] = el_g * 1e3 / args.steps
-        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-        tg = torch.tensor([el_g], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        check_rows(np.array(y_slice), "host-gathered slice")  # what landed in the shared host vector
-        barrier()
-        if rank == 0:  # the caller's view: the whole y, gathered with no collective (rank 0 spot-checks the other slices' rows
-            whole_ok = bool(np.all(np.isfinite(ys.arr)))   # being written at all; each rank checked its own slice above)
-            assert whole_ok
-        gather = {
-            "value": round(2.0 * nnz_total * args.steps / float(tg.item()) / 1e9, 3), "unit": "GFLOP/s",
-            "ms_per_step": round(float(tg.item()) * 1e3 / args.steps, 6),
-            "rank_ms_per_step": [round(float(v), 6) for v in mine.tolist()],
-            "rank0_events_ms_per_step": round(ev_ms_g / args.steps, 6),
-            "x_bytes_per_rank_per_step": int(m.na * 8), "y_bytes_this_rank_per_step": int(m.rows * 8),
-            "pinned": bool(pinned_x and pinned_y),
-            "what": "per step and rank: x H2D from one pinned shared host vector (libspmv/gpu.c:264), the kernels, the rank's y "
-                    "slice D2H straight to its row offset of one shared host vector (gpu.c:285; the host gather); no collective",
-        }
-        if pinned_x:
-            be.host_unregister(xs.arr)
-        if pinned_y:
-            be.host_unregister(ys.arr)
-        del y_slice
-        xs.close(unlink=(rank == 0))
-        ys.close(unlink=(rank == 0))
+        nnz_total = float(m.nnz)
+        if dist is not None:
+            mine = torch.zeros(n_gpus, dtype=torch.float64, device=red_dev)
+            mine[rank] = elapsed * 1e3 / args.steps
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)  # every rank's own ms per step, for the balance of the partition
+            rank_ms = [round(float(v), 6) for v in mine.tolist()]
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            s = torch.tensor([float(m.nnz)], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(s, op=dist.ReduceOp.SUM)
+            nnz_total = float(s.item())
+        # the timed kernel really computed y = A*x: EVERY local row against numpy, outside the timed region
+        y = np.empty(m.rows)
+        be.d2h(y, dy, device)
+        check_rows(np, m.a, m.rowstr, m.colidx, x, y, "kernel")
+        alg_bytes_rank0 = info["algorithmic_bytes"]
+        m_na = m.na
+
+        # N > 1 under a launcher: the same step with the traffic of an ABI call around the kernels (libspmv/gpu.c:264,285)
+        if dist is not None:
+            from lilac_benchmarks_amd.hostgather import SharedVector
+            tag = "hipspmv_bench_%s" % os.environ.get("MASTER_PORT", "0")
+            if rank == 0:
+                xs = SharedVector(tag + "_x", m.na + 2, create=True)
+                xs.arr[:] = x
+                xs.arr.flush()
+                SharedVector(tag + "_y", m.na, create=True).close()
+            barrier()
+            if rank != 0:
+                xs = SharedVector(tag + "_x", m.na + 2)
+            ys = SharedVector(tag + "_y", m.na)
+            pinned_x = be.host_register(xs.arr)
+            pinned_y = be.host_register(ys.arr)
+            y_slice = ys.arr[m.row_begin:m.row_end]
+            dm.time_call(xs.arr, y_slice, dx, dy, max(1, args.warmup))
+            barrier()
+            t_start = time.perf_counter()
+            ev_ms_g = dm.time_call(xs.arr, y_slice, dx, dy, args.steps)
+            torch.cuda.synchronize()
+            el_g = time.perf_counter() - t_start
+            barrier()
+            mine = torch.zeros(n_gpus, dtype=torch.float64, device=red_dev)
+            mine[rank] = el_g * 1e3 / args.steps
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+            tg = torch.tensor([el_g], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            check_rows(np, m.a, m.rowstr, m.colidx, x, np.array(y_slice), "host-gathered slice")  # what landed in the shared host vector
+            barrier()
+            if rank == 0:
+                assert bool(np.all(np.isfinite(ys.arr)))  # the caller's view: the whole y, gathered with no collective
+            gather = {
+                "value": round(2.0 * nnz_total * args.steps / float(tg.item()) / 1e9, 3), "unit": "GFLOP/s",
+                "ms_per_step": round(float(tg.item()) * 1e3 / args.steps, 6),
+                "rank_ms_per_step": [round(float(v), 6) for v in mine.tolist()],
+                "rank0_events_ms_per_step": round(ev_ms_g / args.steps, 6),
+                "x_bytes_per_rank_per_step": int(m.na * 8), "y_bytes_this_rank_per_step": int(m.rows * 8),
+                "pinned": bool(pinned_x and pinned_y),
+                "what": "per step and rank: x H2D from one pinned shared host vector (libspmv/gpu.c:264), the kernels, the rank's y "
+                        "slice D2H straight to its row offset of one shared host vector (gpu.c:285; the host gather); no collective",
+            }
+            if pinned_x:
+                be.host_unregister(xs.arr)
+            if pinned_y:
+                be.host_unregister(ys.arr)
+            del y_slice
+            xs.close(unlink=(rank == 0))
+            ys.close(unlink=(rank == 0))
 
     ms_per_step = elapsed * 1e3 / args.steps
     gflops = 2.0 * nnz_total * args.steps / elapsed / 1e9
     launch_ms = ev_ms / args.steps
-    achieved = info["algorithmic_bytes"] / (launch_ms * 1e-3) / 1e9
+    achieved = alg_bytes_rank0 / (launch_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if n_gpus == 1 and os.path.exists(tpath):
@@ -255,6 +464,7 @@ def main():
         except Exception:
             traffic = None
 
+    na_total = m_na
     line = {
         "metric": "NPB CG class %s SpMV effective GFLOP/s (FP64 CSR y=A*x, HBM-resident; %% of HBM roofline "
                   "in `roofline`, NPB CG MOp/s through the ABI in `npb_cg`)" % cls,
@@ -272,20 +482,21 @@ def main():
         "config": {
             "workload": ("NPB3.3.1 CG class %s matrix (literal restatement of cg.f's makea; pinned by nnz, row-length extrema, "
                          "y[0] and the NPB zeta verification, tests/test_npb.py), "
-                         "na=%d, nnz=%d, one y=A*x per step, A/x/y resident in HBM" % (cls, m.na, int(nnz_total))),
+                         "na=%d, nnz=%d, one y=A*x per step, A/x/y resident in HBM" % (cls, na_total, int(nnz_total))),
             "class": cls,
-            "rows": m.na,
+            "rows": na_total,
             "nnz": int(nnz_total),
             "plan": pkg.abi.PLAN_NAMES[info["plan"]],
             "plan_param": info["plan_param"],
             "launches_per_step": info["n_launches"],
             "parallelism": "1 GPU" if n_gpus == 1 else
                            "block-row partition over %d GPUs (equal nnz), x replicated, no collective" % n_gpus,
+            "processes": ("one process driving %d GPUs through the library (no launcher)" % n_gpus) if inproc else
+                         ("one process per GPU (torch.distributed, %s)" % backend_name if n_gpus > 1 else "one process"),
             "rank_ms_per_step": rank_ms,
             "untimed_steps_before_timing": PREWARM + args.warmup,
-            "prewarm": "%d untimed steps (50 ms of back-to-back products) before the %d warm-up steps: the first hundred launches after an "
-                       "upload run 3-10 %% slower (profiles/r02_kbench_npb_shapes_steady_state.log, r02_kbench_ab_priority_rotation.log)" % (
-                           PREWARM, args.warmup),
+            "prewarm": "%d untimed steps (the 20 `cold` launches, then ~50 ms of back-to-back products) before the %d warm-up steps; "
+                       "the cold figure is in `cold`" % (PREWARM, args.warmup),
         },
         "roofline": {
             "bound": "hbm",
@@ -297,38 +508,66 @@ def main():
             "traffic_source": traffic_src,
             "kernel": "k_%s" % pkg.abi.PLAN_NAMES[info["plan"]],
             "launches_per_step": info["n_launches"],
-            "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
+            "algorithmic_bytes_per_launch": alg_bytes_rank0,
             "launch_us": round(launch_ms * 1e3, 3),
-            "scope": "rank 0's row block" if n_gpus > 1 else "whole matrix",
+            "scope": "the slowest row block (its own algorithmic bytes over its own launch time)" if n_gpus > 1 else "whole matrix",
             # context, not the contract's fraction: what a kernel that only READS memory reaches on an MI355X
             # (tools/streambench.hip, 24 KiB per workgroup: profiles/r01_streambench_read_ceilings.log)
             "measured_read_ceiling": {"GB/s": MEASURED_READ_CEILING_GBS, "frac_of_it": round(achieved / MEASURED_READ_CEILING_GBS, 4),
                                       "source": "profiles/r01_streambench_read_ceilings.log (stored figure)"},
         },
     }
-
+    if cold is not None:
+        line["cold"] = cold
+    if devices_used is not None:
+        line["config"]["devices_used"] = devices_used
+        if devices_used < n_gpus:
+            line["config"]["rehearsal"] = "%d row blocks wrapped onto %d visible GPU(s): the code path of an N-GPU run, not its speed" % (n_gpus, devices_used)
     if gather is not None:
         line["gather_inclusive"] = gather
+    if n_gpus > 1:
         line["config"]["value_is"] = "kernels only, x / y resident in HBM (the contract's figure); gather_inclusive adds the per-call x H2D and y D2H"
+
+    # =============================================================== N > 1: the metric's first term, NPB CG MOp/s
+    if n_gpus > 1:
+        if not inproc:
+            dm.close()
+            be.free(dx, device)
+            be.free(dy, device)
+            m.close()
+            barrier()  # every rank has freed its row block
+        if rank == 0 and not args.no_npb:
+            obj, mfull = npb_through_the_abi(pkg, be, cls, n_gpus, 1, np)
+            line["npb_cg"] = obj
+            if inproc:
+                # the gather-inclusive step, one process: K ABI calls on the full matrix (x to every GPU, kernels, y slices back)
+                xx = np.random.default_rng(12345).standard_normal(mfull.na + 2)
+                yy = np.empty(mfull.na)
+                be.harness(yy, mfull.a, xx, mfull.rowstr, mfull.colidx, mfull.na)  # upload
+                k = max(3, min(args.steps, 20))
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    be.harness(yy, mfull.a, xx, mfull.rowstr, mfull.colidx, mfull.na)
+                el = (time.perf_counter() - t1) / k
+                check_rows(np, mfull.a, mfull.rowstr, mfull.colidx, xx, yy, "ABI call over %d row partitions" % n_gpus)
+                line["gather_inclusive"] = {
+                    "value": round(2.0 * mfull.nnz / el / 1e9, 3), "unit": "GFLOP/s", "ms_per_step": round(el * 1e3, 6), "steps": k,
+                    "what": "one spmv_harness_ call per step from this process (SPMV_HIP_DEVICES): x from pageable host memory into a "
+                            "pinned buffer and from there to every GPU at once (libspmv/gpu.c:264), the kernels, every GPU's y "
+                            "slice back to its row offset of the caller's y (gpu.c:285: the host gather); no collective",
+                }
+                be.release()
+            mfull.close()
+        if dist is not None:
+            dist.barrier()
 
     if rank == 0 and n_gpus == 1 and not args.no_npb:
         be.reset_stats()
         runs = [m.run_cg(be.harness_fn()) for _ in range(max(1, args.npb_repeats))]
         st = be.stats()
         res = sorted(runs, key=lambda r: r["mops"])[len(runs) // 2]  # median run (reference convention: 5 repeats)
-        line["npb_cg"] = {
-            "class": cls, "mops": round(res["mops"], 2), "time_s": round(res["t_bench"], 4),
-            "repeats": len(runs), "mops_all": [round(r["mops"], 1) for r in runs],
-            "verified_all": all(bool(r["verified"]) for r in runs),
-            "time_in_spmv_s": round(res["t_spmv"], 4), "spmv_calls": res["spmv_calls"],
-            "zeta": res["zeta"], "err": res["err"], "verified": bool(res["verified"]),
-            "path": "spmv_harness_ ABI: host x/y every call (PCIe round trip), host vector loops on 1 core",
-            "upload_s": round(st["t_upload"], 4), "init_s": round(st["t_init"], 4),
-            # SURVEY 8(d) "also report": the PCIe-inclusive time of one ABI call (entry -> return: x H2D, kernels, y D2H)
-            "us_per_abi_call": round(res["t_spmv"] / max(1, res["spmv_calls"]) * 1e6, 2),
-            "one_time": "init_s (HIP context + code object, first call of the process) and upload_s (matrix H2D + re-layout, "
-                        "inside the untimed first conj_grad, cg.f:233) are not part of time_s",
-        }
+        line["npb_cg"] = npb_cg_object(m, be, res, st, runs, cls,
+                                       "spmv_harness_ ABI: host x/y every call (PCIe round trip), host vector loops on 1 core")
         be.release()
         # the same benchmark with the opt-in device-resident CG step (vectors never leave the GPU)
         runsd = [m.run_cg_device(be) for _ in range(max(1, args.npb_repeats))]
@@ -365,27 +604,34 @@ def main():
         be.free(dx32, device)
         be.free(dy32, device)
 
+    if rank == 0 and n_gpus == 1 and not args.no_configs:
+        other_configs(pkg, be, np, line)
+
     if rank == 0 and n_gpus == 1 and cls == "C" and not args.no_scale_ref:
         # the workload of the N > 1 runs (class D, BASELINE configs[4]) on this one GPU, whole matrix:
         # the like-for-like 1-GPU point for the strong-scaling series (the headline above stays class C)
         t0 = time.time()
         md = pkg.npb.NpbMatrix("D")
         t_gen = time.time() - t0
+        t0 = time.time()
         dmd = be.matrix(md.a, md.rowstr, md.colidx, md.rows, device=device, cols_hint=md.na)
+        t_up = time.time() - t0
         infd = dmd.info()
         xd = np.random.default_rng(12345).standard_normal(md.na + 2)
         dxd = be.malloc(xd.nbytes, device)
         dyd = be.malloc(md.rows * 8, device)
         be.h2d(dxd, xd, device)
-        dmd.time_device(dxd, dyd, 40)  # untimed (~50 ms): the first passes over a freshly uploaded 7-GB layout run 5-10 % slower
-        ksteps = 20                    # (tools/jobs/r2_xcd.sh: 1245 us for the first 30 launches, 1175 us from then on)
+        cold_d = dmd.time_device(dxd, dyd, 20) / 20
+        dmd.time_device(dxd, dyd, 20)  # untimed: the first passes over a freshly uploaded 7-GB layout run 5-10 % slower
+        ksteps = 20
         msd = dmd.time_device(dxd, dyd, ksteps) / ksteps
         line["scale_ref"] = {
             "workload": "NPB CG class D, whole matrix on 1 GPU (what the N > 1 runs partition)",
             "value": round(2.0 * md.nnz / (msd * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "ms_per_step": round(msd, 6),
             "steps": ksteps, "warmup": 40, "nnz": int(md.nnz), "plan": pkg.abi.PLAN_NAMES[infd["plan"]],
             "roofline_frac": round(infd["algorithmic_bytes"] / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "algorithmic_bytes_per_launch": infd["algorithmic_bytes"], "generated_s": round(t_gen, 1),
+            "cold_ms_per_step": round(cold_d, 6),
+            "algorithmic_bytes_per_launch": infd["algorithmic_bytes"], "generated_s": round(t_gen, 1), "upload_s": round(t_up, 2),
             "launches_per_step": infd["n_launches"], "workgroups": infd["n_blocks"],
         }
         try:  # stored PMC figure of this workload (profiles/traffic.json), not measured by this run
@@ -439,9 +685,10 @@ def main():
                       "rows split by nonzeros (bit-identical to the single-core result)" % (reps_mt, int(used)),
         }
 
-    dm.close()
-    be.free(dx, device)
-    be.free(dy, device)
+    if n_gpus == 1:
+        dm.close()
+        be.free(dx, device)
+        be.free(dy, device)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -119,6 +119,10 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
 int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int reps, void *stream,
                          float *ms_total);
 
+/* One process driving several GPUs: `reps` products of each of n device-resident matrices (the row blocks of one matrix,
+ * one per GPU), launched rep by rep, each on its own device's stream; ms_each[i] = elapsed on matrix i's stream. */
+int spmv_hip_time_multi(spmv_hip_matrix **ms, void *const *x_dev, void *const *y_dev, int n, int reps, float *ms_each);
+
 /*
  * The traffic of one ABI call around the kernel (libspmv/gpu.c:264,285), `reps` times on one stream between two
  * HIP events: x_host -> x_dev (cols elements), y = A x, y_dev -> y_host (the matrix's rows).  For the row-
@@ -169,7 +173,8 @@ int spmv_hip_synchronize(int device);
  * k_stream / k_striped (default 1); 1 non-temporal loads of a/colidx (0); 2-4 TILED geometry (waves per workgroup, LDS
  * bytes per stripe, workgroups aimed for); 5 register sets of k_tiled; 9, 11, 12 STRIPED geometry (workgroups aimed for,
  * stripe groups, most rows per wave range; 0 = choose); 15 STRIPED kernel shape (0 = chosen per matrix, 1 = 16 waves x
- * 128 KiB of x, 2 = 8 waves x 64 KiB).  Diagnostics (ablation bits, clock stamps, fault injection) are not in this
+ * 128 KiB of x, 2 = 8 waves x 64 KiB); 17 who converts to STRIPED (0 = the GPU, from the CSR copy in HBM, the host threads
+ * when it must; 1 = the host; 2 = the GPU or fail).  Diagnostics (ablation bits, clock stamps, fault injection) are not in this
  * library: they live in the debug build, include/spmv_hip_debug.h. */
 void spmv_hip_set_tuning(int key, int value);
 

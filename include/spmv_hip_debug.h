@@ -30,6 +30,12 @@ int spmv_hip_debug_stamps(int device, unsigned long long *out, int n);
  * (pads included), entries of its longest wave, rows}; returns the number of workgroups written, -1 on error */
 int spmv_hip_debug_striped_wgs(const spmv_hip_matrix *m, long long *out, int max_wgs);
 
+/* digests of the five device arrays of a STRIPED layout (tptr, rrow, wgd, col, val): equal iff the bytes are */
+int spmv_hip_debug_striped_digest(const spmv_hip_matrix *m, unsigned long long *out5);
+
+/* one of the five arrays (0 tptr, 1 rrow, 2 wgd, 3 col, 4 val) copied to `out` (at most `bytes`); returns its size in bytes */
+long long spmv_hip_debug_striped_array(const spmv_hip_matrix *m, int which, void *out, long long bytes);
+
 #ifdef __cplusplus
 }
 #endif

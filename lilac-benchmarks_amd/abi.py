@@ -73,6 +73,8 @@ class Backend:
         L.spmv_hip_spmv_device.argtypes = [ctypes.c_void_p] * 4
         L.spmv_hip_time_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.spmv_hip_time_multi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_float)]
         L.spmv_hip_time_call.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
         L.spmv_hip_host_alloc.restype = ctypes.c_void_p
         L.spmv_hip_host_alloc.argtypes = [ctypes.c_size_t]
@@ -197,6 +199,17 @@ class Backend:
 
     def host_unregister(self, arr):
         self.lib.spmv_hip_host_unregister(_ptr(arr))
+
+    def time_multi(self, matrices, x_devs, y_devs, reps):
+        """spmv_hip_time_multi: reps products of each device-resident matrix, rep by rep; ms elapsed on each one's stream."""
+        n = len(matrices)
+        hs = (ctypes.c_void_p * n)(*[m.h for m in matrices])
+        xs = (ctypes.c_void_p * n)(*x_devs)
+        ys = (ctypes.c_void_p * n)(*y_devs)
+        ms = (ctypes.c_float * n)()
+        if self.lib.spmv_hip_time_multi(hs, xs, ys, n, int(reps), ms) != 0:
+            raise RuntimeError(self.last_error())
+        return [float(v) for v in ms]
 
     def matrix(self, a, rowstr, colidx, rows, device=0, row_begin=0, row_end=None, cols_hint=0):
         return Matrix(self, a, rowstr, colidx, rows, device, row_begin, row_end, cols_hint)

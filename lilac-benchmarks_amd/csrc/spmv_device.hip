@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -36,10 +37,13 @@ namespace {
 thread_local char g_err[512] = "";
 
 #define SPMV_MAX_DEVICES 16
+#define SPMV_Y_CHUNKS_MAX 16
 struct DevCtx {
     bool ready = false;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;     /* y chunks on their way to the host while later chunks are computed */
     hipEvent_t ev[2] = {nullptr, nullptr}; /* spmv_hip_time_device: created once, not inside the timed region */
+    hipEvent_t chunk_ev[SPMV_Y_CHUNKS_MAX] = {};
 };
 DevCtx g_dev[SPMV_MAX_DEVICES];
 std::mutex g_dev_mu;
@@ -494,7 +498,12 @@ extern "C" void spmvd_set_relayout(int on) { g_relayout = on ? 1 : 0; }
  * threads of a row partition side by side, so atomics; set them only while no upload is in flight */
 static std::atomic<int> g_stripe_wgs{0}, g_stripe_groups{0}, g_stripe_wave_rows{SPMV_STRIPE_WAVE_ROWS}, g_stripe_shape{0};
 
-/* Builds the STRIPED layout; same conventions as ensure_tiled. */
+/* Builds the STRIPED layout; same conventions as ensure_tiled.  The conversion runs on the GPU, from the CSR copy that
+ * is already in HBM (spmv_striped_gpu.hip), unless the matrix is not a case for it (rows not sorted by column, more than
+ * 512 stripes) or tuning key 17 says host: then on host threads (spmv_striped.c) from the caller's arrays or, when those
+ * are not at hand, from a download of the CSR copy.  Both builders produce the same bytes. */
+static std::atomic<int> g_striped_builder{0}; /* 0: device, host when it must; 1: host; 2: device or fail (tests) */
+
 static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *host_col, int64_t first,
                           bool auto_choice)
 {
@@ -507,31 +516,8 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         }
         return 0;
     }
-    void *tmp_a = nullptr;
-    int *tmp_c = nullptr;
-    if (!host_a) {
-        tmp_a = malloc((size_t)(m->nnz ? m->nnz : 1) * m->elem);
-        tmp_c = (int *)malloc((size_t)(m->nnz ? m->nnz : 1) * sizeof(int));
-        if (!tmp_a || !tmp_c) {
-            free(tmp_a), free(tmp_c);
-            spmv_set_error("out of host memory for the STRIPED conversion");
-            m->striped_rc = -3;
-            return -3;
-        }
-        hipStream_t st = g_dev[m->device].stream;
-        if (m->nnz > 0) {
-            HIPCHK(hipMemcpyAsync(tmp_a, m->d_val, (size_t)m->nnz * m->elem, hipMemcpyDeviceToHost, st),
-                   { free(tmp_a); free(tmp_c); return -1; });
-            HIPCHK(hipMemcpyAsync(tmp_c, m->d_col, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost, st),
-                   { free(tmp_a); free(tmp_c); return -1; });
-        }
-        HIPCHK(hipStreamSynchronize(st), { free(tmp_a); free(tmp_c); return -1; });
-        host_a = tmp_a;
-        host_col = tmp_c;
-        first = 0;
-    }
-    const int64_t shift = first - ((int64_t)m->h_rowstr_local[0] - 1);
     spmv_striped_host th;
+    memset(&th, 0, sizeof th);
     spmv_striped_opts so;
     spmv_striped_default_opts(&so);
     const int shape = g_stripe_shape.load() ? g_stripe_shape.load() : spmv_striped_choose_shape(&m->st, m->elem, m->cols);
@@ -544,23 +530,80 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         so.target_wgs = g_stripe_wgs.load();
     so.groups = g_stripe_groups.load();
     so.wave_rows = g_stripe_wave_rows.load();
-    int rc = m->cols < 16 ? -2
-                          : spmv_striped_build((const char *)host_a + shift * m->elem, m->h_rowstr_local,
-                                               host_col + shift, 0, m->rows, m->cols, m->elem, &so, &th);
-    free(tmp_a), free(tmp_c);
+
+    void *d_c = nullptr, *d_v = nullptr; /* the packed arrays, when the device built them */
+    int rc = -4;
+    const int builder = g_striped_builder.load();
+    if (m->cols < 16)
+        rc = -2;
+    else if (builder != 1)
+        rc = spmv_striped_build_device(m->d_rowptr, m->d_col, m->d_val, m->rows, m->cols, m->elem, m->nnz, &so,
+                                       g_dev[m->device].stream, &th, &d_c, &d_v);
+    if (rc == -1) { /* a HIP error inside the device builder: its message stands */
+        m->striped_rc = -1;
+        return -1;
+    }
+    if (rc == -4 && builder == 2) {
+        spmv_set_error("the device builder declined this matrix");
+        return -1;
+    }
+    if (rc == -4) { /* the host builder */
+        void *tmp_a = nullptr;
+        int *tmp_c = nullptr;
+        if (!host_a) {
+            tmp_a = malloc((size_t)(m->nnz ? m->nnz : 1) * m->elem);
+            tmp_c = (int *)malloc((size_t)(m->nnz ? m->nnz : 1) * sizeof(int));
+            if (!tmp_a || !tmp_c) {
+                free(tmp_a), free(tmp_c);
+                spmv_set_error("out of host memory for the STRIPED conversion");
+                m->striped_rc = -3;
+                return -3;
+            }
+            hipStream_t st = g_dev[m->device].stream;
+            if (m->nnz > 0) {
+                HIPCHK(hipMemcpyAsync(tmp_a, m->d_val, (size_t)m->nnz * m->elem, hipMemcpyDeviceToHost, st),
+                       { free(tmp_a); free(tmp_c); return -1; });
+                HIPCHK(hipMemcpyAsync(tmp_c, m->d_col, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost, st),
+                       { free(tmp_a); free(tmp_c); return -1; });
+            }
+            HIPCHK(hipStreamSynchronize(st), { free(tmp_a); free(tmp_c); return -1; });
+            host_a = tmp_a;
+            host_col = tmp_c;
+            first = 0;
+        }
+        const int64_t shift = first - ((int64_t)m->h_rowstr_local[0] - 1);
+        rc = spmv_striped_build((const char *)host_a + shift * m->elem, m->h_rowstr_local, host_col + shift, 0, m->rows,
+                                m->cols, m->elem, &so, &th);
+        free(tmp_a), free(tmp_c);
+    }
+
     /* many (row, stripe) pairs are empty: the columns are local to the rows, x gathers already
      * hit in cache and the STREAM kernel is the better plan (measured: 73 us vs 133 us; with only two
      * stripes a banded matrix leaves just under half of the pairs empty, hence 40 %, while scattered
-     * columns at the 1.6-per-segment limit of spmv_plan_choose leave 20 %); or one dense row makes a tile
-     * many times longer than the rest (STREAM cuts long rows into segments) */
-    m->striped_mostly_filler = rc == 0 && (th.n_dummies * 5 >= 2 * (int64_t)th.S * m->rows || th.skewed);
+     * columns at the 1.6-per-segment limit of spmv_plan_choose leave 20 %) -- but only when the empties are more than
+     * scattered columns would leave: a row of n entries thrown at S stripes misses S (1 - 1/S)^n of them, and a matrix of
+     * many short rows (heavy-tailed row lengths: tools/dispatch_audit.py, 40 000 rows, 3.4 M nonzeros, STRIPED 20.6 us
+     * against STREAM 27.8) has its empties for that reason, not because its columns are local; or one dense row makes
+     * a wave's stream many times longer than the rest (STREAM cuts long rows into segments) */
+    bool local_columns = false;
+    if (rc == 0 && th.n_dummies * 5 >= 2 * (int64_t)th.S * m->rows) {
+        double expected = 0.0; /* empties if every row's columns were scattered uniformly */
+        const double lq = th.S > 1 ? log(1.0 - 1.0 / (double)th.S) : -1e9;
+        for (int r = 0; r < m->rows; ++r)
+            expected += (double)th.S * exp(lq * (double)(m->h_rowstr_local[r + 1] - m->h_rowstr_local[r]));
+        local_columns = (double)th.n_dummies > 1.5 * expected + 0.05 * (double)th.S * m->rows;
+    }
+    m->striped_mostly_filler = rc == 0 && (local_columns || th.skewed);
     if (auto_choice && m->striped_mostly_filler) {
         spmv_striped_free(&th);
+        (void)hipFree(d_c), (void)hipFree(d_v);
+        d_c = d_v = nullptr;
         rc = -2;
     }
     m->striped_rc = rc == -1 ? -3 : rc;
-    if (rc == -1) {
-        spmv_set_error("out of host memory for the STRIPED conversion");
+    if (rc == -1 || rc == -3) {
+        spmv_set_error("out of memory for the STRIPED conversion");
+        m->striped_rc = -3;
         return -3;
     }
     if (rc == -2) {
@@ -570,7 +613,7 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     const size_t ntp = (size_t)th.n_ranges * ((size_t)th.GM + 1);
     const size_t n_alloc = (size_t)th.n_packed + SPMV_TILE_PAD;
     const size_t pbytes = th.NG > 1 ? (size_t)th.NG * (size_t)m->rows * (size_t)m->elem + 64 : 0;
-    void *d_t = nullptr, *d_r = nullptr, *d_c = nullptr, *d_v = nullptr, *d_p = nullptr, *d_g = nullptr;
+    void *d_t = nullptr, *d_r = nullptr, *d_p = nullptr, *d_g = nullptr;
     hipError_t e = hipMalloc(&d_t, ntp * sizeof(int32_t));
     if (e == hipSuccess)
         e = hipMalloc(&d_r, ((size_t)th.n_ranges * 2 + 2) * sizeof(int32_t));
@@ -578,9 +621,9 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         e = hipMalloc(&d_g, ((size_t)th.n_wg * 4 + 4) * sizeof(int32_t));
     if (e == hipSuccess)
         e = hipMemcpy(d_g, th.wgd, (size_t)th.n_wg * 4 * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
+    if (e == hipSuccess && !d_c)
         e = hipMalloc(&d_c, n_alloc * sizeof(uint16_t));
-    if (e == hipSuccess)
+    if (e == hipSuccess && !d_v)
         e = hipMalloc(&d_v, n_alloc * (size_t)m->elem);
     if (e == hipSuccess && pbytes)
         e = hipMalloc(&d_p, pbytes);
@@ -588,9 +631,9 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         e = hipMemcpy(d_t, th.tptr, ntp * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(d_r, th.rrow, (size_t)th.n_ranges * 2 * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
+    if (e == hipSuccess && th.col)
         e = hipMemcpy(d_c, th.col, n_alloc * sizeof(uint16_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
+    if (e == hipSuccess && th.val)
         e = hipMemcpy(d_v, th.val, n_alloc * (size_t)m->elem, hipMemcpyHostToDevice);
     if (e == hipSuccess && take_injected_oom())
         e = hipErrorOutOfMemory;
@@ -807,7 +850,8 @@ int spmv_hip_matrix_refresh_values(spmv_hip_matrix *m, const void *a, const int 
                return -1);
     HIPCHK(hipStreamSynchronize(st), return -1); /* the caller may write `a` again as soon as this returns */
     if (m->have_striped || m->have_tiled) {
-        /* the re-laid-out copies hold the values in their own order: packed again (the plan is kept when that works) */
+        /* the re-laid-out copies hold the values in their own order: the one in use is packed again (the plan is kept
+         * when that works), one that is not in use is dropped (its values are stale) */
         const bool was_striped = m->plan == SPMV_HIP_PLAN_STRIPED, was_tiled = m->plan == SPMV_HIP_PLAN_TILED;
         free_relayouts(m);
         int rc = 0;
@@ -1009,6 +1053,112 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
     return 0;
 }
 
+/*
+ * y = A x with the rows cut into `chunks` launches, each chunk's rows of y setting off for host memory on a second
+ * stream as soon as its launch is done, so that the D2H copy of a long y (SparseBench 170^3: 39 MB, 0.7 ms at PCIe
+ * speed) runs beside the kernels that still compute (libspmv/gpu.c:285 copies y after the whole product).  Only for the
+ * plans whose launches write whole, contiguous runs of rows (STREAM and its long-row kernels, VECTOR).  Returns 1 when
+ * the product and the copy were done this way (both complete on return), 0 when the plan does not cut into row chunks
+ * (nothing was launched), -1 on error.
+ */
+int spmvd_spmv_y_overlapped(spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *y_host, int chunks)
+{
+    if (!m || m->rows == 0 || (m->plan != SPMV_HIP_PLAN_STREAM && m->plan != SPMV_HIP_PLAN_VECTOR))
+        return 0;
+    if (chunks > SPMV_Y_CHUNKS_MAX)
+        chunks = SPMV_Y_CHUNKS_MAX;
+    const int units = m->plan == SPMV_HIP_PLAN_STREAM ? m->sp.nblk : m->rows;
+    if (chunks < 2 || units < chunks)
+        return 0;
+    if (use_device(m->device))
+        return -1;
+    DevCtx &dc = g_dev[m->device];
+    if (!dc.copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&dc.copy_stream, hipStreamNonBlocking), return -1);
+        for (int c = 0; c < SPMV_Y_CHUNKS_MAX; ++c)
+            HIPCHK(hipEventCreateWithFlags(&dc.chunk_ev[c], hipEventDisableTiming), return -1);
+    }
+    hipStream_t st = dc.stream;
+    spmv_dev_csr d;
+    d.rowptr = m->d_rowptr, d.colidx = m->d_col, d.val = m->d_val, d.rows = m->rows, d.nnz = m->nnz, d.elem_size = m->elem;
+    int rc = 0;
+    if (m->plan == SPMV_HIP_PLAN_STREAM && m->sp.nseg > 0) /* rows too long for a row block: their y first */
+        rc = spmvk_long(&d, m->d_seg, m->sp.nseg, m->d_lrow, m->sp.nlrow, m->d_partials, x_dev, y_dev, st);
+    int row_lo[SPMV_Y_CHUNKS_MAX + 1];
+    for (int c = 0; c < chunks && !rc; ++c) {
+        const int u0 = (int)((int64_t)units * c / chunks), u1 = (int)((int64_t)units * (c + 1) / chunks);
+        if (m->plan == SPMV_HIP_PLAN_STREAM) {
+            row_lo[c] = m->sp.blk[2 * u0];
+            row_lo[c + 1] = m->sp.blk[2 * u1];
+            rc = spmvk_stream(&d, m->d_blk + 2 * u0, u1 - u0, x_dev, y_dev, st);
+        } else {
+            row_lo[c] = u0, row_lo[c + 1] = u1;
+            spmv_dev_csr dd = d;
+            dd.rowptr = m->d_rowptr + u0;
+            dd.rows = u1 - u0;
+            rc = spmvk_vector(&dd, m->param, nullptr, u1 - u0, x_dev, (char *)y_dev + (size_t)u0 * m->elem, st);
+        }
+        if (!rc)
+            HIPCHK(hipEventRecord(dc.chunk_ev[c], st), return -1);
+    }
+    if (rc) {
+        spmv_set_error("kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return -1;
+    }
+    /* every launch is queued; now the copies, each behind its chunk's event (a copy to pageable memory holds the host
+     * thread until it is done, which is why they come last) */
+    for (int c = 0; c < chunks; ++c) {
+        const size_t off = (size_t)row_lo[c] * m->elem, len = (size_t)(row_lo[c + 1] - row_lo[c]) * m->elem;
+        HIPCHK(hipStreamWaitEvent(dc.copy_stream, dc.chunk_ev[c], 0), return -1);
+        if (len)
+            HIPCHK(hipMemcpyAsync((char *)y_host + off, (const char *)y_dev + off, len, hipMemcpyDeviceToHost, dc.copy_stream),
+                   return -1);
+    }
+    HIPCHK(hipStreamSynchronize(dc.copy_stream), return -1);
+    HIPCHK(hipStreamSynchronize(st), return -1);
+    return 1;
+}
+
+/*
+ * One process, several GPUs: `reps` products of each of n device-resident matrices (usually the row blocks of one
+ * matrix, one per GPU), launched rep by rep on each matrix's own stream; ms_each[i] = matrix i's elapsed time between
+ * HIP events on ITS stream.  All streams have drained on return.  bench.py times its single-process N-GPU runs with it.
+ */
+int spmv_hip_time_multi(spmv_hip_matrix **ms, void *const *x_dev, void *const *y_dev, int n, int reps, float *ms_each)
+{
+    if (!ms || n <= 0 || n > 64 || reps <= 0 || !ms_each)
+        return -1;
+    hipEvent_t ev[64][2];
+    for (int i = 0; i < n; ++i) {
+        if (!ms[i] || use_device(ms[i]->device))
+            return -1;
+        HIPCHK(hipEventCreate(&ev[i][0]), return -1);
+        HIPCHK(hipEventCreate(&ev[i][1]), return -1);
+    }
+    int rc = 0;
+    for (int i = 0; i < n && !rc; ++i) {
+        HIPCHK(hipSetDevice(ms[i]->device), rc = -1);
+        HIPCHK(hipEventRecord(ev[i][0], g_dev[ms[i]->device].stream), rc = -1);
+    }
+    for (int r = 0; r < reps && !rc; ++r)
+        for (int i = 0; i < n && !rc; ++i)
+            rc = spmv_hip_spmv_device(ms[i], x_dev[i], y_dev[i], nullptr);
+    for (int i = 0; i < n && !rc; ++i) {
+        HIPCHK(hipSetDevice(ms[i]->device), rc = -1);
+        HIPCHK(hipEventRecord(ev[i][1], g_dev[ms[i]->device].stream), rc = -1);
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!rc) {
+            HIPCHK(hipSetDevice(ms[i]->device), rc = -1);
+            HIPCHK(hipEventSynchronize(ev[i][1]), rc = -1);
+            HIPCHK(hipEventElapsedTime(&ms_each[i], ev[i][0], ev[i][1]), rc = -1);
+        }
+        (void)hipEventDestroy(ev[i][0]);
+        (void)hipEventDestroy(ev[i][1]);
+    }
+    return rc;
+}
+
 int spmv_hip_time_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, int reps, void *stream,
                          float *ms_total)
 {
@@ -1089,6 +1239,63 @@ int spmv_hip_debug_stamps(int device, unsigned long long *out, int n)
     return spmvk_striped_stamps(out, n);
 }
 
+/* debug build: FNV-1a digests of the five arrays of a STRIPED layout (tptr, rrow, wgd, col, val incl. the look-ahead
+ * padding), downloaded: two layouts are the same bytes iff these agree (the device builder against the host builder) */
+int spmv_hip_debug_striped_digest(const spmv_hip_matrix *m, unsigned long long *out5)
+{
+    if (!m || !m->have_striped || use_device(m->device))
+        return -1;
+    const spmv_dev_striped &d = m->ds;
+    size_t n_packed = 0;
+    {
+        int32_t last = 0;
+        const size_t ntp = (size_t)d.n_ranges * ((size_t)d.GM + 1);
+        if (hipMemcpy(&last, d.tptr + ntp - 1, 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        n_packed = (size_t)last;
+    }
+    const size_t n_alloc = n_packed + SPMV_TILE_PAD;
+    const void *ptr[5] = {d.tptr, d.rrow, d.wgd, d.col, d.val};
+    const size_t len[5] = {(size_t)d.n_ranges * ((size_t)d.GM + 1) * 4, (size_t)d.n_ranges * 8, (size_t)d.n_wg * 16, n_alloc * 2,
+                           n_alloc * (size_t)d.elem};
+    for (int k = 0; k < 5; ++k) {
+        unsigned char *h = (unsigned char *)malloc(len[k] ? len[k] : 1);
+        if (!h || hipMemcpy(h, ptr[k], len[k], hipMemcpyDeviceToHost) != hipSuccess) {
+            free(h);
+            return -1;
+        }
+        unsigned long long x = 1469598103934665603ull;
+        const unsigned long long *w = (const unsigned long long *)h;
+        for (size_t i = 0; i < len[k] / 8; ++i) /* word-wise FNV-1a: a digest, not a standard hash */
+            x = (x ^ w[i]) * 1099511628211ull;
+        for (size_t i = len[k] / 8 * 8; i < len[k]; ++i)
+            x = (x ^ h[i]) * 1099511628211ull;
+        out5[k] = x;
+        free(h);
+    }
+    return 0;
+}
+
+/* debug build: one of the five arrays of a STRIPED layout (0 tptr, 1 rrow, 2 wgd, 3 col, 4 val) copied to `out` (at most
+ * `bytes`); returns the array's size in bytes, -1 on error */
+long long spmv_hip_debug_striped_array(const spmv_hip_matrix *m, int which, void *out, long long bytes)
+{
+    if (!m || !m->have_striped || which < 0 || which > 4 || use_device(m->device))
+        return -1;
+    const spmv_dev_striped &d = m->ds;
+    int32_t last = 0;
+    const size_t ntp = (size_t)d.n_ranges * ((size_t)d.GM + 1);
+    if (hipMemcpy(&last, d.tptr + ntp - 1, 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    const size_t n_alloc = (size_t)last + SPMV_TILE_PAD;
+    const void *ptr[5] = {d.tptr, d.rrow, d.wgd, d.col, d.val};
+    const size_t len[5] = {ntp * 4, (size_t)d.n_ranges * 8, (size_t)d.n_wg * 16, n_alloc * 2, n_alloc * (size_t)d.elem};
+    const size_t n = len[which] < (size_t)bytes ? len[which] : (size_t)bytes;
+    if (out && n && hipMemcpy(out, ptr[which], n, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    return (long long)len[which];
+}
+
 /* debug build: what each workgroup of a STRIPED layout holds -- per workgroup {first stripe, end stripe, group, entries of
  * all its waves (pads included), entries of its longest wave, rows}; returns the number of workgroups, -1 on error */
 int spmv_hip_debug_striped_wgs(const spmv_hip_matrix *m, long long *out, int max_wgs)
@@ -1136,6 +1343,8 @@ void spmv_hip_set_tuning(int key, int value)
         g_stripe_groups = value;
     else if (key == 12 && value >= 64 && value <= SPMV_STRIPE_WAVE_ROWS && value % 64 == 0)
         g_stripe_wave_rows = value;
+    else if (key == 17 && value >= 0 && value <= 2)
+        g_striped_builder = value; /* 0: the device builds the STRIPED layout (the host when it must), 1: host, 2: device or fail */
     else if (key == 15 && value >= 0 && value <= 2)
         g_stripe_shape = value; /* 0: chosen per matrix, 1: 16 waves x 128 KiB, 2: 8 waves x 64 KiB */
 #ifdef SPMV_HIP_DEBUG_BUILD

@@ -45,6 +45,8 @@
  *                      compare: no page protection, every call compares the arrays byte for byte.
  *   SPMV_HIP_ZEROCOPY = 1 (default) | 0     vectors up to 1 MB cross PCIe through kernels
  *                                           reading / writing pinned host memory instead of DMA
+ *   SPMV_HIP_YOVERLAP = 1 (default) | 0     a y of 4 MB or more leaves in row chunks while later chunks compute
+ *                                           (STREAM / VECTOR plans, one part)
  *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped
  *   SPMV_HIP_DEVICES = number of GPUs to row-partition over (default 1; "all")
  *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
@@ -141,7 +143,7 @@ static struct {
     int dev_inited;  /* HIP runtime initialised, device context exists                 */
     int dispatch;    /* DISPATCH_AUTO / _DEVICE / _HOST                                */
     double host_spent; /* seconds this process has spent in host products so far       */
-    int cache, pin, stats, verbose, zero_copy;
+    int cache, pin, stats, verbose, zero_copy, y_overlap;
     int plan, plan_param;
     int ndev, nparts, nslots;
     long page;
@@ -555,6 +557,7 @@ static void lazy_init(void)
     if (G.dispatch == DISPATCH_AUTO && (G.plan != SPMV_HIP_PLAN_AUTO || getenv("SPMV_HIP_PARTS") || getenv("SPMV_HIP_DEVICES")))
         G.dispatch = DISPATCH_DEVICE; /* who names a kernel or a row partition wants the device */
     G.zero_copy = env_int("SPMV_HIP_ZEROCOPY", 1);
+    G.y_overlap = env_int("SPMV_HIP_YOVERLAP", 1);
     G.stats = env_int("SPMV_HIP_STATS", 0);
     G.verbose = env_int("SPMV_HIP_VERBOSE", 0);
     G.nslots = env_int("SPMV_HIP_CACHE_SLOTS", 4);
@@ -931,10 +934,16 @@ static void slot_upload(slot *sl, const void *a, const int *rowstr, const int *c
 static void refresh_values(slot *sl, const void *a, const int *colidx)
 {
     const double t0 = spmv_now();
+    const int short_lived = sl->uses_since_refresh < SHORT_LIVED_USES;
+    if (!sl->values_volatile && (short_lived || sl->probing) && G.plan == SPMV_HIP_PLAN_AUTO)
+        /* about to become volatile: a re-laid-out plan would pack its second copy again on every call (STRIPED costs
+         * 0.1 s per class-C-sized matrix and pays off only over hundreds of products); the CSR kernels from here on */
+        for (int p = 0; p < sl->nparts; ++p)
+            if (spmv_hip_matrix_set_plan(sl->part[p], SPMV_HIP_PLAN_STREAM, 0) != 0)
+                die("switching a volatile matrix to the CSR kernels failed: %s", spmv_hip_last_error());
     for (int p = 0; p < sl->nparts; ++p)
         if (spmv_hip_matrix_refresh_values(sl->part[p], a, colidx) != 0)
             die("refreshing the values of a cached matrix failed (part %d of %d): %s", p, sl->nparts, spmv_hip_last_error());
-    const int short_lived = sl->uses_since_refresh < SHORT_LIVED_USES;
     sl->uses_since_refresh = 0;
     if (sl->values_volatile) {
         if (++sl->volatile_calls >= sl->probe_every) { /* look again: keep a copy, the next call compares */
@@ -961,6 +970,26 @@ static void refresh_values(slot *sl, const void *a, const int *colidx)
 }
 
 /* ---------------------------------------------------------------- pinned transfers */
+
+/* a long vector into / out of the pinned staging buffer on a few host threads (12 MB: 1.2 ms on one, 0.3 ms on six) */
+typedef struct cpy_ctx {
+    char *d;
+    const char *s;
+} cpy_ctx;
+static void cpy_range(int64_t lo, int64_t hi, void *v)
+{
+    const cpy_ctx *c = (const cpy_ctx *)v;
+    memcpy(c->d + lo, c->s + lo, (size_t)(hi - lo));
+}
+static void par_memcpy(void *d, const void *s, size_t n)
+{
+    if (n < ((size_t)4 << 20)) {
+        memcpy(d, s, n);
+        return;
+    }
+    cpy_ctx c = {(char *)d, (const char *)s};
+    spmv_parallel_for((int64_t)n, (int64_t)2 << 20, cpy_range, &c);
+}
 
 static void *stage_buf(void **buf, size_t *cap, size_t need)
 {
@@ -1101,6 +1130,8 @@ static int pinned_in_place(const void *p, size_t bytes)
  * in place, else our staging buffer.  Returns 0 when the call was served this way.
  */
 #define ZERO_COPY_MAX_BYTES ((size_t)1 << 20)
+#define Y_OVERLAP_MIN_BYTES ((size_t)4 << 20) /* from here a y travels in row chunks beside the kernels */
+#define Y_OVERLAP_CHUNKS 8
 
 static int harness_zero_copy(slot *sl, void *ov, const void *iv, size_t xbytes, size_t ybytes)
 {
@@ -1180,6 +1211,10 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
             slot_arm_guard(sl, 0, sl->protect);
             if (sl->uncacheable)
                 full = 1;
+            else if (G.plan == SPMV_HIP_PLAN_AUTO) /* the plan the matrix would have got had it never been volatile */
+                for (int p = 0; p < sl->nparts; ++p)
+                    if (spmv_hip_matrix_set_plan(sl->part[p], SPMV_HIP_PLAN_AUTO, 0) != 0)
+                        die("re-planning a matrix whose values have settled failed: %s", spmv_hip_last_error());
         }
         if (full) {
             if (G.cache != CACHE_OFF && own) {
@@ -1248,11 +1283,17 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
         return NULL;
     }
 
-    /* x: host -> every part's device (libspmv/gpu.c:264) */
+    /*
+     * x: host -> every part's device (libspmv/gpu.c:264).  One part: a large heap vector is handed to the runtime as
+     * it is (use_in_place).  Several parts on several GPUs: the runtime's pageable path holds the host thread for the
+     * length of every copy, so N devices would receive x one after the other; instead x goes into the pinned staging
+     * buffer once (a few host threads) and from there to all devices at the same time, each over its own PCIe link.
+     */
+    const int multi = sl->nparts > 1 && G.pin != PIN_PAGEABLE;
     const void *xsrc = iv;
-    if (!use_in_place(iv, xbytes)) {
+    if (multi ? !pinned_in_place(iv, xbytes) : !use_in_place(iv, xbytes)) {
         void *xs = stage_buf(&G.xstage, &G.xstage_n, xbytes);
-        memcpy(xs, iv, xbytes);
+        par_memcpy(xs, iv, xbytes);
         xsrc = xs;
     }
     for (int p = 0; p < sl->nparts; ++p)
@@ -1263,6 +1304,26 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
         t1 = spmv_now();
         G.st.t_x_h2d += t1 - t0;
         t0 = t1;
+    }
+
+    /* a long y of one part: in row chunks, each on its way to the host while the next are computed (the y D2H of
+     * SparseBench 170^3 takes longer than its kernel) */
+    if (sl->nparts == 1 && !detailed && G.y_overlap && ybytes >= Y_OVERLAP_MIN_BYTES) {
+        char *yd = (char *)ov;
+        const int staged = !use_in_place(ov, ybytes);
+        if (staged)
+            yd = (char *)stage_buf(&G.ystage, &G.ystage_n, ybytes);
+        const int rc = spmvd_spmv_y_overlapped(sl->part[0], sl->dx[0], sl->dy[0], yd, Y_OVERLAP_CHUNKS);
+        if (rc < 0)
+            die("spmvd_spmv_y_overlapped: %s", spmv_hip_last_error());
+        if (rc == 1) {
+            if (staged)
+                par_memcpy(ov, yd, ybytes);
+            G.st.calls++;
+            G.st.t_total += spmv_now() - t_in;
+            pthread_mutex_unlock(&g_mu);
+            return NULL;
+        }
     }
 
     /* y_part = A_part * x, one launch sequence per part, each on its device's stream */
@@ -1279,7 +1340,7 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
     /* y: each part's slice straight to its place in ov -- the host gather (libspmv/gpu.c:285) */
     char *ydst = (char *)ov;
     int y_staged = 0;
-    if (!use_in_place(ov, ybytes)) {
+    if (multi ? !pinned_in_place(ov, ybytes) : !use_in_place(ov, ybytes)) {
         ydst = (char *)stage_buf(&G.ystage, &G.ystage_n, ybytes);
         y_staged = 1;
     }
@@ -1291,7 +1352,7 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
     for (int p = 0; p < sl->nparts; ++p)
         CHECK(spmvd_stream_sync(sl->part_dev[p]));
     if (y_staged)
-        memcpy(ov, ydst, ybytes);
+        par_memcpy(ov, ydst, ybytes);
     if (detailed)
         G.st.t_y_d2h += spmv_now() - t0;
 

@@ -161,6 +161,18 @@ void spmv_striped_default_opts(spmv_striped_opts *o);
  * stripes (two per CU) */
 int spmv_striped_choose_shape(const spmv_row_stats *st, int elem_size, int cols);
 void spmv_striped_geometry(int rows, int cols, int elem_size, const spmv_striped_opts *o, spmv_striped_host *t);
+/* the pieces of the conversion that are decisions, not data movement: shared by the host builder and the device builder
+ * (spmv_striped_gpu.hip), which therefore produce the same layout byte for byte */
+void spmv_striped_plan_geometry(int rows, int cols, int elem_size, int64_t nnz, const spmv_striped_opts *opts, spmv_striped_host *t);
+void spmv_striped_alloc_blocks(const spmv_striped_opts *opts, int rows, const int64_t *gent, int *gnb, spmv_striped_host *t);
+void spmv_striped_cut_all(const spmv_striped_opts *opts, int rows, const uint32_t *wgt, const int *gnb, spmv_striped_host *t);
+int spmv_striped_tile_starts(const int64_t *tsize, const int64_t *rfill, int64_t nnz, spmv_striped_host *t);
+/* the conversion on the GPU, from the device-resident CSR block (spmv_striped_gpu.hip): 0 (t: geometry and host copies of
+ * tptr / rrow / wgd; the packed arrays in device memory), -2 / -3 as the host builder, -4 = not a case for it (the caller
+ * runs the host builder), -1 a HIP error */
+int spmv_striped_build_device(const int *d_rowptr, const int *d_col, const void *d_val, int rows, int cols, int elem_size,
+                              int64_t nnz, const spmv_striped_opts *opts, void *stream, spmv_striped_host *t,
+                              void **d_tcol_out, void **d_tval_out);
 /* opts == NULL: the defaults */
 int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int r0, int r1, int cols,
                        int elem_size, const spmv_striped_opts *opts, spmv_striped_host *t);
@@ -227,6 +239,9 @@ void spmvd_host_unregister(void *p);
 int spmvd_copy_h2d_async(int device, void *dst_dev, const void *src, size_t bytes);
 int spmvd_copy_d2h_async(int device, void *dst, const void *src_dev, size_t bytes);
 int spmvd_stream_sync(int device);
+/* y = A x in row chunks, every chunk's y on its way to y_host (second stream) while the next chunks compute: 1 done
+ * (product and copy complete), 0 the plan does not cut into row chunks (nothing launched), -1 error */
+int spmvd_spmv_y_overlapped(struct spmv_hip_matrix *m, const void *x_dev, void *y_dev, void *y_host, int chunks);
 /* 0: the automatic plan choice of matrices created BY THE CALLING THREAD from now on skips the re-laid-out plans */
 void spmvd_set_relayout(int on);
 /* zero-copy: the device-side address of pinned host memory (hipHostMalloc'ed or registered), NULL

@@ -280,17 +280,20 @@ static int cpus_allowed(void)
  */
 int spmv_build_threads(void)
 {
-    static int n = 0;
-    if (n == 0) {
+    static int n = 0; /* the parts of a row partition build side by side: read and written with atomics; every thread
+                         that finds it unset computes the same value */
+    int have = __atomic_load_n(&n, __ATOMIC_RELAXED);
+    if (have == 0) {
         int want = cpus_allowed();
         if (want > 32)
             want = 32;
         const char *e = getenv("SPMV_HIP_BUILD_THREADS");
         if (e && atoi(e) > 0)
             want = atoi(e);
-        n = want < 1 ? 1 : (want > 64 ? 64 : want);
+        have = want < 1 ? 1 : (want > 64 ? 64 : want);
+        __atomic_store_n(&n, have, __ATOMIC_RELAXED);
     }
-    return n;
+    return have;
 }
 
 /* fn(lo, hi, ctx) over [0, n) in contiguous chunks, one per thread; serial when n < 2 * grain or

@@ -436,7 +436,11 @@ static void choose_geometry(int s_min, int s_cap, int ng_max, int nb_min, int ta
 {
     int best = ng_max < 1 ? 1 : ng_max, best_s = s_min;
     double best_cost = 1e300;
-    const int ng_top = target / (nb_min > 0 ? nb_min : 1) > 0 ? target / (nb_min > 0 ? nb_min : 1) : 1;
+    int ng_top = target / (nb_min > 0 ? nb_min : 1); /* as many groups as the accumulators allow ... */
+    if (ng_top > s_cap)
+        ng_top = s_cap;                               /* ... but never more groups than stripes */
+    if (ng_top < 1)
+        ng_top = 1;
     for (int cand = ng_top; cand >= 1 && cand >= ng_top - 32; --cand) {
         for (int variant = 1; variant >= 0; --variant) { /* on a tie: the stripes that divide into the groups */
             int S = s_min;
@@ -459,6 +463,136 @@ static void choose_geometry(int s_min, int s_cap, int ng_max, int nb_min, int ta
     *ng_out = best, *s_out = best_s;
 }
 
+/* stripes, groups, stripe width: everything the layout's shape depends on, from the matrix's dimensions alone (shared by the
+ * host builder below and the device builder, spmv_striped_gpu.hip) */
+void spmv_striped_plan_geometry(int rows, int cols, int elem_size, int64_t nnz, const spmv_striped_opts *opts, spmv_striped_host *t)
+{
+    spmv_striped_geometry(rows, cols, elem_size, opts, t);
+    if (opts->groups <= 0 && t->S > 1 && rows > 0) {
+        const int64_t per_block = (int64_t)opts->wpb * opts->wave_rows;
+        int ng = t->NG, ns = t->S;
+        /* a stripe narrower than 4/5 of what the buffer holds is not worth the equal division */
+        const int s_cap = t->S + t->S / 4 > 32768 ? 32768 : t->S + t->S / 4;
+        choose_geometry(t->S, s_cap, t->NG, (int)((rows + per_block - 1) / per_block), opts->target_wgs < 1 ? 1 : opts->target_wgs,
+                        opts->wpb, nnz, 64 * (int64_t)t->EPL, rows, elem_size, opts->stripes > 0, &ng, &ns);
+        spmv_striped_opts o2 = *opts;
+        o2.groups = ng;
+        o2.stripes = ns;
+        spmv_striped_geometry(rows, cols, elem_size, &o2, t);
+    }
+}
+
+/*
+ * Row blocks per group: in proportion to the group's entries (groups of 5 and of 4 stripes must not get the same number
+ * of workgroups: the larger ones would run a quarter longer), at least what the accumulators demand, no more waves than
+ * rows; the largest remainders take what is left of the target.  gent[g] = the group's entries, fillers included.
+ * Fills gnb[NG], t->n_wg, t->n_ranges, t->NB.
+ */
+void spmv_striped_alloc_blocks(const spmv_striped_opts *opts, int rows, const int64_t *gent, int *gnb, spmv_striped_host *t)
+{
+    const int NG = t->NG, WPB = t->WPB;
+    int64_t total = 0;
+    for (int g = 0; g < NG; ++g)
+        total += gent[g];
+    const int target = opts->target_wgs < 1 ? 1 : opts->target_wgs;
+    const int64_t per_block = (int64_t)WPB * opts->wave_rows;
+    const int nb_min = (int)((rows + per_block - 1) / per_block);
+    int nb_max = rows / WPB; /* no point in more waves than rows */
+    if (nb_max < nb_min)
+        nb_max = nb_min;
+    int used = 0;
+    for (int g = 0; g < NG; ++g) {
+        int nb = total > 0 ? (int)((int64_t)target * gent[g] / total) : target / NG;
+        nb = nb < nb_min ? nb_min : (nb > nb_max ? nb_max : nb);
+        gnb[g] = nb;
+        used += nb;
+    }
+    while (used < target) { /* largest remainder first; ties to the lower group: deterministic */
+        int best = -1;
+        double best_rem = -1.0;
+        for (int g = 0; g < NG; ++g) {
+            if (gnb[g] >= nb_max)
+                continue;
+            const double rem = (total > 0 ? (double)target * (double)gent[g] / (double)total : 0.0) - gnb[g];
+            if (rem > best_rem)
+                best_rem = rem, best = g;
+        }
+        if (best < 0)
+            break;
+        gnb[best]++;
+        ++used;
+    }
+    t->n_wg = used;
+    t->n_ranges = used * WPB;
+    t->NB = 0;
+    for (int g = 0; g < NG; ++g)
+        t->NB = gnb[g] > t->NB ? gnb[g] : t->NB;
+}
+
+/* the wave ranges (t->rrow) and workgroup descriptors (t->wgd) of all groups from the per-group row weights wgt[NG][rows];
+ * both arrays must hold n_ranges * 2 and n_wg * 4 entries */
+void spmv_striped_cut_all(const spmv_striped_opts *opts, int rows, const uint32_t *wgt, const int *gnb, spmv_striped_host *t)
+{
+    const int NG = t->NG, S = t->S, WPB = t->WPB;
+    int q = 0;
+    for (int g = 0; g < NG; ++g) {
+        cut_rows(wgt + (size_t)g * rows, rows, gnb[g] * WPB, opts->wave_rows, t->rrow + (size_t)q * WPB * 2);
+        for (int rb = 0; rb < gnb[g]; ++rb, ++q) {
+            t->wgd[4 * q + 0] = (int)((int64_t)g * S / NG);
+            t->wgd[4 * q + 1] = (int)((int64_t)(g + 1) * S / NG);
+            t->wgd[4 * q + 2] = g;
+            t->wgd[4 * q + 3] = rb;
+        }
+    }
+}
+
+/*
+ * Tile starts in stream order -- workgroup (g-major), wave, stripe of the group -- from the padded tile sizes
+ * tsize[n_ranges][GM]; fills t->tptr, n_packed, n_dummies, max_tile, skewed.  0, or -2: the stream does not fit 32-bit
+ * offsets, or more than 1/8 of it would be filler (the matrix is too sparse per stripe for this plan).
+ */
+int spmv_striped_tile_starts(const int64_t *tsize, const int64_t *rfill, int64_t nnz, spmv_striped_host *t)
+{
+    const int nr = t->n_ranges, GM = t->GM, WPB = t->WPB;
+    const int64_t sub = 64 * (int64_t)t->EPL;
+    int64_t total = 0, fillers = 0, longest = 0, longest_wave = 0;
+    for (int u = 0; u < nr; ++u) {
+        fillers += rfill[u];
+        const int32_t *d = t->wgd + (size_t)(u / WPB) * 4;
+        const int ns = d[1] - d[0];
+        int32_t *tp = t->tptr + (size_t)u * ((size_t)GM + 1);
+        const int64_t wave0 = total;
+        for (int si = 0; si <= GM; ++si) {
+            if (total > 0x7fffffff - 65536)
+                return -2;
+            tp[si] = (int32_t)total;
+            if (si < ns) {
+                const int64_t len = tsize[(size_t)u * GM + si];
+                total += len;
+                longest = len > longest ? len : longest;
+            }
+        }
+        longest_wave = total - wave0 > longest_wave ? total - wave0 : longest_wave;
+    }
+    t->n_packed = total;
+    t->n_dummies = fillers;
+    t->max_tile = longest;
+    if (fillers * 8 > nnz)
+        return -2;
+    /*
+     * A (row, stripe) segment is never split between waves: one dense row makes its wave's stream many times longer than
+     * the others', and the launch lasts as long as that wave needs -- about 1.1 ns per entry (a wave alone streams a
+     * 256-entry sub-window in 0.28 us).  That is harmless while the launch would take as long anyway, and still the better
+     * plan while it beats the CSR kernels' 8 ps per nonzero on scattered columns (tools/dispatch_audit.py, the heavy-tailed
+     * shape: 40 000 rows, one of 20 000 nonzeros among 3.4 M: STRIPED 21.8 us, STREAM 27.7); beyond that -- one wave
+     * holding more than 1/137 of all entries, 30 times its share at 4096 waves -- the automatic choice declines.
+     * (Round 2 declined from twice the mean TILE, which lost that shape by 27 %.)
+     */
+    (void)sub;
+    t->skewed = (double)longest_wave * 1.1e-9 > (double)nnz * 8.0e-12 && longest_wave > 4 * (total / (nr > 0 ? nr : 1)) + sub;
+    return 0;
+}
+
 /*
  * rowstr / colidx / a: the caller's 1-based CSR; rows [r0,r1) are converted.
  * Returns 0, -1 (out of memory), -2 (not representable / not worth it).
@@ -473,20 +607,7 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
         spmv_striped_default_opts(&dflt);
         opts = &dflt;
     }
-    spmv_striped_geometry(rows, cols, elem_size, opts, t);
-    if (opts->groups <= 0 && t->S > 1 && rows > 0) {
-        const int64_t per_block = (int64_t)opts->wpb * opts->wave_rows;
-        int ng = t->NG, ns = t->S;
-        /* a stripe narrower than 1/4 of the buffer is not worth the equal division */
-        const int s_cap = t->S + t->S / 4 > 32768 ? 32768 : t->S + t->S / 4;
-        choose_geometry(t->S, s_cap, t->NG, (int)((rows + per_block - 1) / per_block), opts->target_wgs < 1 ? 1 : opts->target_wgs,
-                        opts->wpb, (int64_t)rowstr[r1] - rowstr[r0], 64 * (int64_t)t->EPL, rows, elem_size,
-                        opts->stripes > 0, &ng, &ns);
-        spmv_striped_opts o2 = *opts;
-        o2.groups = ng;
-        o2.stripes = ns;
-        spmv_striped_geometry(rows, cols, elem_size, &o2, t);
-    }
+    spmv_striped_plan_geometry(rows, cols, elem_size, (int64_t)rowstr[r1] - rowstr[r0], opts, t);
     const int S = t->S, NG = t->NG, GM = t->GM, WPB = t->WPB;
     if (rows <= 0 || opts->wave_rows < 64 || opts->wave_rows % 64 || S > 32768 /* fastdiv_do */ ||
         (int64_t)NG * rows > ((int64_t)1 << 28))
@@ -525,52 +646,14 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
         goto out;
     }
 
-    /*
-     * Row blocks per group: in proportion to the group's entries (groups of 5 and of 4 stripes must not get
-     * the same number of workgroups: the larger ones would run a quarter longer), at least what the
-     * accumulators demand, no more waves than rows; the largest remainders take what is left of the target.
-     */
-    {
-        int64_t total = 0;
-        for (int g = 0; g < NG; ++g) {
-            const uint32_t *w = c.wgt + (size_t)g * rows;
-            int64_t e = 0;
-            for (int r = 0; r < rows; ++r)
-                e += w[r];
-            gent[g] = e;
-            total += e;
-        }
-        const int target = opts->target_wgs < 1 ? 1 : opts->target_wgs;
-        const int64_t per_block = (int64_t)WPB * opts->wave_rows;
-        const int nb_min = (int)((rows + per_block - 1) / per_block);
-        int nb_max = rows / WPB; /* no point in more waves than rows */
-        if (nb_max < nb_min)
-            nb_max = nb_min;
-        int used = 0;
-        for (int g = 0; g < NG; ++g) {
-            int nb = total > 0 ? (int)((int64_t)target * gent[g] / total) : target / NG;
-            nb = nb < nb_min ? nb_min : (nb > nb_max ? nb_max : nb);
-            gnb[g] = nb;
-            used += nb;
-        }
-        while (used < target) { /* largest remainder first; ties to the lower group: deterministic */
-            int best = -1;
-            double best_rem = -1.0;
-            for (int g = 0; g < NG; ++g) {
-                if (gnb[g] >= nb_max)
-                    continue;
-                const double rem = (total > 0 ? (double)target * (double)gent[g] / (double)total : 0.0) - gnb[g];
-                if (rem > best_rem)
-                    best_rem = rem, best = g;
-            }
-            if (best < 0)
-                break;
-            gnb[best]++;
-            ++used;
-        }
-        t->n_wg = used;
-        t->n_ranges = used * WPB;
+    for (int g = 0; g < NG; ++g) {
+        const uint32_t *w = c.wgt + (size_t)g * rows;
+        int64_t e = 0;
+        for (int r = 0; r < rows; ++r)
+            e += w[r];
+        gent[g] = e;
     }
+    spmv_striped_alloc_blocks(opts, rows, gent, gnb, t);
     const int nr = t->n_ranges;
     if ((int64_t)nr * GM > ((int64_t)1 << 26)) {
         rc = -2;
@@ -583,21 +666,7 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
     t->tptr = (int32_t *)calloc((size_t)nr * ((size_t)GM + 1), sizeof(int32_t));
     if (!c.tsize || !c.rfill || !t->rrow || !t->wgd || !t->tptr)
         goto out;
-    {
-        int q = 0;
-        for (int g = 0; g < NG; ++g) {
-            cut_rows(c.wgt + (size_t)g * rows, rows, gnb[g] * WPB, opts->wave_rows, t->rrow + (size_t)q * WPB * 2);
-            for (int rb = 0; rb < gnb[g]; ++rb, ++q) {
-                t->wgd[4 * q + 0] = c.gs0[g];
-                t->wgd[4 * q + 1] = c.gs0[g + 1];
-                t->wgd[4 * q + 2] = g;
-                t->wgd[4 * q + 3] = rb;
-            }
-        }
-        t->NB = 0;
-        for (int g = 0; g < NG; ++g)
-            t->NB = gnb[g] > t->NB ? gnb[g] : t->NB;
-    }
+    spmv_striped_cut_all(opts, rows, c.wgt, gnb, t);
     free(c.wgt);
     c.wgt = NULL;
 
@@ -607,39 +676,9 @@ int spmv_striped_build(const void *a, const int *rowstr, const int *colidx, int 
         goto out;
     }
 
-    /* tile starts in stream order: workgroup (g-major), wave, stripe of the group */
-    {
-        int64_t total = 0, fillers = 0, longest = 0, ntiles = 0;
-        for (int u = 0; u < nr; ++u) {
-            fillers += c.rfill[u];
-            const int32_t *d = t->wgd + (size_t)(u / WPB) * 4;
-            const int ns = d[1] - d[0];
-            int32_t *tp = t->tptr + (size_t)u * ((size_t)GM + 1);
-            for (int si = 0; si <= GM; ++si) {
-                if (total > 0x7fffffff - 65536) {
-                    rc = -2;
-                    goto out;
-                }
-                tp[si] = (int32_t)total;
-                if (si < ns) {
-                    const int64_t len = c.tsize[(size_t)u * GM + si];
-                    total += len;
-                    longest = len > longest ? len : longest;
-                    ++ntiles;
-                }
-            }
-        }
-        t->n_packed = total;
-        t->n_dummies = fillers;
-        t->max_tile = longest;
-        if (fillers * 8 > nnz) { /* more than 1/8 of the stream would be filler: the matrix is too sparse per
-                                    stripe for this plan */
-            rc = -2;
-            goto out;
-        }
-        /* a (row, stripe) segment is never split between waves: one dense row makes its tile many times longer
-         * than the rest, and every wave of its workgroup waits for it at the stripe's end */
-        t->skewed = longest * ntiles > 2 * total + c.SUB * ntiles;
+    if (spmv_striped_tile_starts(c.tsize, c.rfill, nnz, t) != 0) {
+        rc = -2;
+        goto out;
     }
 
     {
