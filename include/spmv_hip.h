@@ -29,9 +29,13 @@ enum {
     SPMV_HIP_PLAN_TILED = 5,   /* column stripes of x held in LDS, one row per lane; sums each  */
                                /* row stripe by stripe in stored order: bit-identical to the    */
                                /* reference when a row's columns are sorted                     */
-    SPMV_HIP_PLAN_STRIPED = 6  /* 2-D: a workgroup = (group of column stripes, row block); one stripe */
+    SPMV_HIP_PLAN_STRIPED = 6, /* 2-D: a workgroup = (group of column stripes, row block); one stripe */
                                /* of x in LDS at a time, row sums carried in registers across the  */
                                /* group, one partial sum per (group, row), added in group order     */
+    SPMV_HIP_PLAN_BLOCKED = 7  /* column blocks of 2 MB of x, entries block-major, XCD c % 8 works on   */
+                               /* block c (its gathers hit its own L2); one sum per (row, block)       */
+                               /* segment, added per row in block order: for short rows with scattered */
+                               /* columns over a long x (SparseBench), where STRIPED has nothing to gain */
 };
 
 /* Opaque device-resident matrix (CSR block + execution plan) on one GPU. */

@@ -31,6 +31,7 @@
 #include "spmv_internal.h"
 
 extern "C" void spmvk_set_tuning(int key, int value);
+extern "C" void spmvk_blocked_set_wgs(int per_xcd);
 
 namespace {
 
@@ -117,6 +118,10 @@ struct spmv_hip_matrix {
     bool have_striped = false;
     bool striped_mostly_filler = false;
     size_t striped_bytes = 0;
+    /* BLOCKED (built on demand, on the device) */
+    bool have_blocked = false;
+    int blocked_rc = 0;
+    spmv_dev_blocked db{};
     int striped_rc = 0;
     spmv_dev_striped ds{};
 };
@@ -319,6 +324,11 @@ static void free_relayouts(spmv_hip_matrix *m)
         if (m->ds.partial)
             (void)hipFree(m->ds.partial);
         m->have_striped = false;
+    }
+    if (m->have_blocked) {
+        m->device_bytes -= m->db.bytes;
+        spmv_blocked_free(&m->db);
+        m->have_blocked = false;
     }
     if (m->have_tiled) {
         m->device_bytes -= m->tiled_bytes;
@@ -674,6 +684,29 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     return 0;
 }
 
+/* Builds the BLOCKED layout from the device's CSR copy (spmv_blocked.hip): 0, -2 not representable, -3 no memory, -1 error */
+static int ensure_blocked(spmv_hip_matrix *m)
+{
+    if (m->have_blocked)
+        return 0;
+    int rc = spmv_blocked_build_device(m->d_rowptr, m->d_col, m->d_val, m->rows, m->cols, m->elem, m->nnz,
+                                       g_dev[m->device].stream, &m->db);
+    if (rc == 0 && take_injected_oom()) {
+        spmv_blocked_free(&m->db);
+        rc = -3;
+    }
+    m->blocked_rc = rc;
+    if (rc == -2)
+        spmv_set_error("matrix not representable in the BLOCKED layout (more than 512 column blocks, or more than 64 and rows not sorted by column)");
+    else if (rc == -3)
+        spmv_set_error("out of memory for the BLOCKED layout");
+    if (rc)
+        return rc;
+    m->device_bytes += m->db.bytes;
+    m->have_blocked = true;
+    return 0;
+}
+
 spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const int *colidx, int rows,
                                         int elem_size, int device, int row_begin, int row_end,
                                         int cols_hint)
@@ -807,7 +840,7 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     HIPCHK(hipStreamSynchronize(st), FAIL());
 
     spmv_plan_choose(&m->st, elem_size, m->cols, &m->plan, &m->param);
-    if (!g_relayout && (m->plan == SPMV_HIP_PLAN_TILED || m->plan == SPMV_HIP_PLAN_STRIPED)) {
+    if (!g_relayout && (m->plan == SPMV_HIP_PLAN_TILED || m->plan == SPMV_HIP_PLAN_STRIPED || m->plan == SPMV_HIP_PLAN_BLOCKED)) {
         m->plan = SPMV_HIP_PLAN_STREAM; /* the caller expects to upload this matrix again soon */
         m->param = SPMV_STREAM_CAP;
     }
@@ -822,6 +855,15 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
     }
     if (m->plan == SPMV_HIP_PLAN_STRIPED) {
         int rc = ensure_striped(m, a, colidx, first, true);
+        if (rc == -2 || rc == -3) {
+            m->plan = SPMV_HIP_PLAN_STREAM;
+            m->param = SPMV_STREAM_CAP;
+        } else if (rc) {
+            FAIL();
+        }
+    }
+    if (m->plan == SPMV_HIP_PLAN_BLOCKED) {
+        int rc = ensure_blocked(m);
         if (rc == -2 || rc == -3) {
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
@@ -849,13 +891,16 @@ int spmv_hip_matrix_refresh_values(spmv_hip_matrix *m, const void *a, const int 
                               hipMemcpyHostToDevice, st),
                return -1);
     HIPCHK(hipStreamSynchronize(st), return -1); /* the caller may write `a` again as soon as this returns */
-    if (m->have_striped || m->have_tiled) {
+    if (m->have_striped || m->have_tiled || m->have_blocked) {
         /* the re-laid-out copies hold the values in their own order: the one in use is packed again (the plan is kept
          * when that works), one that is not in use is dropped (its values are stale) */
         const bool was_striped = m->plan == SPMV_HIP_PLAN_STRIPED, was_tiled = m->plan == SPMV_HIP_PLAN_TILED;
+        const bool was_blocked = m->plan == SPMV_HIP_PLAN_BLOCKED;
         free_relayouts(m);
         int rc = 0;
-        if (was_striped)
+        if (was_blocked)
+            rc = ensure_blocked(m);
+        else if (was_striped)
             rc = ensure_striped(m, colidx ? a : nullptr, colidx, m->first, false);
         else if (was_tiled)
             rc = ensure_tiled(m, colidx ? a : nullptr, colidx, m->first, false);
@@ -890,6 +935,18 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
         }
+        if (m->plan == SPMV_HIP_PLAN_BLOCKED && ensure_blocked(m)) {
+            if (m->blocked_rc != -2 && m->blocked_rc != -3)
+                return -1;
+            m->plan = SPMV_HIP_PLAN_STREAM;
+            m->param = SPMV_STREAM_CAP;
+        }
+        break;
+    case SPMV_HIP_PLAN_BLOCKED:
+        if (ensure_blocked(m))
+            return -1;
+        m->plan = plan;
+        m->param = m->db.CB;
         break;
     case SPMV_HIP_PLAN_TILED:
         if (ensure_tiled(m, nullptr, nullptr, 0, false))
@@ -937,6 +994,7 @@ static int n_launches(const spmv_hip_matrix *m)
     int longk = m->sp.nseg > 0 ? 1 + (m->sp.nlrow > 0) : 0;
     switch (m->plan) {
     case SPMV_HIP_PLAN_STRIPED: return m->ds.NG > 1 ? 2 : 1;
+    case SPMV_HIP_PLAN_BLOCKED: return 2;
     case SPMV_HIP_PLAN_STREAM: return 1 + longk;
     case SPMV_HIP_PLAN_BINNED: {
         int n = longk;
@@ -965,6 +1023,7 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     out->mean_row_len = m->st.mean_len;
     out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED     ? m->dt.B
                     : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.n_wg
+                    : m->plan == SPMV_HIP_PLAN_BLOCKED ? m->db.n_units
                                                        : m->sp.nblk;
     out->n_long_rows = m->sp.n_long_rows;
     out->n_launches = n_launches(m);
@@ -1013,6 +1072,7 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
     int rc = 0;
     switch (m->plan) {
     case SPMV_HIP_PLAN_ORDERED: rc = spmvk_ordered(&d, x_dev, y_dev, st); break;
+    case SPMV_HIP_PLAN_BLOCKED: rc = spmvk_blocked(&m->db, x_dev, y_dev, st); break;
     case SPMV_HIP_PLAN_STRIPED:
     case SPMV_HIP_PLAN_TILED:
         if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0) {
@@ -1343,6 +1403,8 @@ void spmv_hip_set_tuning(int key, int value)
         g_stripe_groups = value;
     else if (key == 12 && value >= 64 && value <= SPMV_STRIPE_WAVE_ROWS && value % 64 == 0)
         g_stripe_wave_rows = value;
+    else if (key == 18)
+        spmvk_blocked_set_wgs(value); /* BLOCKED phase 1: workgroups per XCD */
     else if (key == 17 && value >= 0 && value <= 2)
         g_striped_builder = value; /* 0: the device builds the STRIPED layout (the host when it must), 1: host, 2: device or fail */
     else if (key == 15 && value >= 0 && value <= 2)

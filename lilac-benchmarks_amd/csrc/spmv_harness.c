@@ -47,7 +47,7 @@
  *                                           reading / writing pinned host memory instead of DMA
  *   SPMV_HIP_YOVERLAP = 1 (default) | 0     a y of 4 MB or more leaves in row chunks while later chunks compute
  *                                           (STREAM / VECTOR plans, one part)
- *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped
+ *   SPMV_HIP_PLAN    = auto (default) | ordered | stream | vector[:L] | binned | tiled | striped | blocked
  *   SPMV_HIP_DEVICES = number of GPUs to row-partition over (default 1; "all")
  *   SPMV_HIP_PARTS   = row partitions per call (default = devices); more parts
  *                      than devices wraps around -- lets the multi-GPU code path
@@ -540,8 +540,10 @@ static void lazy_init(void)
             G.plan = SPMV_HIP_PLAN_TILED;
         else if (!strcmp(v, "striped"))
             G.plan = SPMV_HIP_PLAN_STRIPED;
+        else if (!strcmp(v, "blocked"))
+            G.plan = SPMV_HIP_PLAN_BLOCKED;
         else if (strcmp(v, "auto"))
-            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped", v);
+            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped|blocked", v);
     }
     G.dispatch = DISPATCH_AUTO;
     if ((v = getenv("SPMV_HIP_DISPATCH"))) {
@@ -1308,17 +1310,16 @@ static void *harness(void *ov, const void *a, const void *iv, const int *rowstr,
 
     /* a long y of one part: in row chunks, each on its way to the host while the next are computed (the y D2H of
      * SparseBench 170^3 takes longer than its kernel) */
-    if (sl->nparts == 1 && !detailed && G.y_overlap && ybytes >= Y_OVERLAP_MIN_BYTES) {
+    /* ... when y is pinned where it lies (static storage under SPMV_HIP_PIN=auto: the Fortran callers' COMMON vectors; any
+     * vector under =register): then the chunks are true DMA transfers beside the kernels (SparseBench 170^3, 201 calls:
+     * 0.70 -> 0.63 s).  Into pageable memory the runtime's copy path holds the host thread and the chunks cost more than
+     * they hide (0.57 -> 0.69 s; profiles/r03_sb170_y_overlap_by_pin_mode.log), so a heap vector gets one copy as before. */
+    if (sl->nparts == 1 && !detailed && G.y_overlap && ybytes >= Y_OVERLAP_MIN_BYTES && pinned_in_place(ov, ybytes)) {
         char *yd = (char *)ov;
-        const int staged = !use_in_place(ov, ybytes);
-        if (staged)
-            yd = (char *)stage_buf(&G.ystage, &G.ystage_n, ybytes);
         const int rc = spmvd_spmv_y_overlapped(sl->part[0], sl->dx[0], sl->dy[0], yd, Y_OVERLAP_CHUNKS);
         if (rc < 0)
             die("spmvd_spmv_y_overlapped: %s", spmv_hip_last_error());
         if (rc == 1) {
-            if (staged)
-                par_memcpy(ov, yd, ybytes);
             G.st.calls++;
             G.st.t_total += spmv_now() - t_in;
             pthread_mutex_unlock(&g_mu);

@@ -216,6 +216,26 @@ typedef struct spmv_dev_striped {
     int elem, W, S, WPB, NB, NG, GM, EPL, n_wg, n_ranges, wave_rows, rows, cols;
     int xbytes; /* LDS stripe capacity the layout was built for */
 } spmv_dev_striped;
+/* BLOCKED (spmv_blocked.hip): entries block-major (column blocks of SPMV_BLOCKED_XBYTES of x), one sum per (row, block)
+ * segment, one row mask per (block, 64-row group) cell */
+#define SPMV_BLOCKED_XBYTES (2 << 20) /* bytes of x per column block: half an XCD's L2 */
+typedef struct spmv_dev_blocked {
+    void *bval;                    /* T[nnz + pad], block-major                                              */
+    unsigned int *bcol;            /* 0-based column; bit 31 = last entry of its (row, block) segment        */
+    int *cell_ent, *cell_seg;      /* [nblk * nrg + 1] exclusive scans: entries / segments before the cell   */
+    unsigned long long *cell_mask; /* [nblk * nrg] which of the group's 64 rows have a segment in the block  */
+    int *unit_cell;                /* [n_units * 2] (first cell, end cell) of phase 1's work units            */
+    int *blk_unit0;                /* [nblk + 1] first unit of each block                                    */
+    void *seg_sum;                 /* T[nseg] scratch, rewritten by every product                            */
+    int elem, rows, cols, nblk, nrg, CB, n_units;
+    int64_t nnz, nseg;
+    size_t bytes;
+} spmv_dev_blocked;
+int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, const void *d_val, int rows, int cols, int elem_size,
+                              int64_t nnz, void *stream, spmv_dev_blocked *out);
+void spmv_blocked_free(spmv_dev_blocked *d);
+int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *stream);
+
 struct spmv_hip_matrix;
 /* y = A x plus block partials of y . v when the plan can fold them in (STRIPED): returns the number
  * of partials (one per wave range when a workgroup walks every stripe, else one per 256 rows; <= rows + 16), 0 = not folded (run a separate dot), -1 = error */

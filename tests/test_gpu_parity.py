@@ -66,7 +66,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
             try:
                 m.set_plan(plan, param)
             except RuntimeError as e:
-                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED) and "not representable" in str(e):
+                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED, pkg.PLAN_BLOCKED) and "not representable" in str(e):
                     skipped.append(plan)  # a chunk above 65535 entries, mostly filler: AUTO falls back to STREAM for such matrices
                     continue
                 raise
@@ -86,7 +86,8 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
 
 
 def all_plans(pkg):
-    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0)]
+    P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0),
+         (pkg.PLAN_BLOCKED, 0)]
     P += [(pkg.PLAN_VECTOR, l) for l in (1, 2, 4, 8, 16, 32, 64)]
     return P
 
@@ -1212,6 +1213,58 @@ def test_striped_on_shapes_the_automatic_choice_declines(pkg, backend, oracle):
                         assert np.array_equal(bits(y), bits(oracle.spmv(a, x, rs, ci, rows))), name
             finally:
                 m.close()
+
+
+def test_blocked_plan(pkg, backend, oracle):
+    """The BLOCKED plan (csrc/spmv_blocked.hip): entries block-major over 2-MB column blocks of x, one sum per (row, block)
+    segment, rows added in block order.  Its own shapes: several column blocks (x of 5-40 MB), short rows (SparseBench-
+    like), rows that span many groups of 64 entries inside one block (a carry per group), empty rows, more rows than a
+    multiple of 64, a row count below 64; f64 and f32; results within the CSR bar, the same bits on every repetition and
+    after a value refresh; a matrix with unsorted rows is refused."""
+    rng = np.random.default_rng(97)
+    for dtype in (np.float64, np.float32):
+        cases = {
+            "sparsebench_60": matgen.sparsebench_like(98, 60, dtype),                              # 216 000 rows, one block
+            "wide_short_rows": matgen.random_csr(99, 70001, 3_000_000, 5, dtype, empty_frac=0.1, spread=0.6),   # 12 / 6 blocks
+            "wide_long_rows": matgen.random_csr(100, 900, 2_500_000, 700, dtype, spread=0.5),       # segments of ~70 entries
+            "few_rows": matgen.random_csr(101, 37, 1_000_000, 300, dtype, spread=0.2),
+            "one_long_row": matgen.csr_from_lengths(rng, [3] * 100 + [200000] + [2] * 200, 700_000, dtype),
+        }
+        for name, (rs, ci, a) in cases.items():
+            rows = rs.size - 1
+            x = rng.standard_normal(int(ci.max())).astype(dtype)
+            y_ref = oracle.spmv(a, x, rs, ci, rows)
+            absum = oracle.absum(a, x, rs, ci, rows)
+            m = backend.matrix(a, rs, ci, rows)
+            try:
+                m.set_plan(pkg.PLAN_BLOCKED, 0)
+                inf = m.info()
+                assert inf["plan"] == pkg.PLAN_BLOCKED and inf["n_launches"] == 2
+                y = m.spmv_host(x)
+                assert_close_rows(y, y_ref, absum, np.diff(rs), dtype, name, CSR)
+                for _ in range(3):
+                    assert np.array_equal(bits(m.spmv_host(x)), bits(y)), name
+                a2 = (a * dtype(1.5)).astype(dtype)
+                m.refresh_values(a2, ci)
+                assert m.info()["plan"] == pkg.PLAN_BLOCKED
+                assert_close_rows(m.spmv_host(x), oracle.spmv(a2, x, rs, ci, rows), oracle.absum(a2, x, rs, ci, rows), np.diff(rs),
+                                  dtype, name + " after a value refresh", CSR)
+            finally:
+                m.close()
+    # rows whose columns are not sorted (the SparseBench matrix as the Fortran reader sees it, quirk N1): fine up to 64
+    # column blocks, refused beyond (f32 blocks hold 524288 columns: 40 M columns = 77 blocks)
+    rs, ci, a = matgen.random_csr(102, 30000, 3_000_000, 12, np.float64, sort_cols=False, distinct=False)
+    x = rng.standard_normal(int(ci.max()))
+    m = backend.matrix(a, rs, ci, 30000)
+    m.set_plan(pkg.PLAN_BLOCKED, 0)
+    assert_close_rows(m.spmv_host(x), oracle.spmv(a, x, rs, ci, 30000), oracle.absum(a, x, rs, ci, 30000), np.diff(rs), np.float64,
+                      "unsorted rows", CSR)
+    m.close()
+    rs, ci, a = matgen.random_csr(103, 3000, 40_000_000, 30, np.float32, sort_cols=False)
+    m = backend.matrix(a, rs, ci, 3000)
+    with pytest.raises(RuntimeError, match="not representable"):
+        m.set_plan(pkg.PLAN_BLOCKED, 0)
+    m.close()
 
 
 def test_no_room_for_the_second_copy_is_not_fatal(pkg):

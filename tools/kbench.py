@@ -35,8 +35,10 @@ def build_case(pkg, name, dtype):
         k = np.arange(m.nnz, dtype=np.int64) - np.repeat(m.rowstr[:-1].astype(np.int64) - 1, lens)
         ci = ((rowid + k) % m.na + 1).astype(np.int32)
         return m.rowstr.copy(), ci, m.a.astype(dtype), None
-    if name.startswith("sb"):
-        return matgen.sparsebench_like(170, int(name[2:]), dtype) + (None,)
+    if name.startswith("sb"):  # the C generator of the SparseBench counterpart (host/callers.c sb_generate): seconds, not half a minute
+        m = pkg.callers.sb_generate(int(name[2:]))
+        rs, ci, a = m.arrays()
+        return rs, ci, a.astype(dtype), m
     if name.startswith("rmat"):
         return matgen.rmat_graph(20, int(name[4:]), 16, dtype, values="normal") + (None,)
     if name.startswith("grid"):
@@ -86,7 +88,7 @@ def main():
     be.set_tuning(12, args.swrows)
     groups = [int(v) for v in args.sgroups.split(",")]
     be.set_tuning(11, groups[0])
-    plans = [("striped", pkg.PLAN_STRIPED, 0), ("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
+    plans = [("striped", pkg.PLAN_STRIPED, 0), ("blocked", pkg.PLAN_BLOCKED, 0), ("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
              ("vec16", pkg.PLAN_VECTOR, 16), ("vec8", pkg.PLAN_VECTOR, 8), ("vec4", pkg.PLAN_VECTOR, 4),
              ("vec1", pkg.PLAN_VECTOR, 1), ("binned", pkg.PLAN_BINNED, 0), ("ordered", pkg.PLAN_ORDERED, 0),
              ("auto", pkg.PLAN_AUTO, 0)]
@@ -211,6 +213,9 @@ def main():
             be.set_tuning(11, groups[0])
             be.free(dx)
             be.free(dy)
+            if case.startswith("sb") and keep is not None:
+                del rs, ci, a
+                pkg.callers.free(keep)
             del keep
 
 
