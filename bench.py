@@ -177,7 +177,8 @@ def other_configs(pkg, be, np, line):
     be.reset_stats()
     t1 = time.perf_counter()
     levels = 0
-    sources = np.nonzero(np.diff(rs) >= 8)[0][:: max(1, g.rows // 64)][:16]  # 16 vertices that have somewhere to go
+    cand = np.nonzero(np.diff(rs) >= 8)[0]
+    sources = cand[:: max(1, cand.size // 16)][:16]  # 16 vertices that have somewhere to go
     for src in sources:
         lv, dist = C.bfs_run(g, be.harness_fn(), int(src))
         levels += lv

@@ -102,11 +102,29 @@ static int dispatch_scenario(void)
         spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
         spmv_hip_get_stats(&s);
         EXPECT((long long)s.host_calls == host_before && s.uploads == 1); /* stays on the device, cached */
+        /* a second matrix of the same size, now that the context exists: on the host until it has spent what its upload
+         * costs (10 ms + 6 MB at 20 GB/s = 10.3 ms of estimated host time: 19 products of 520.2 us), then on the device */
+        {
+            csr m2 = make(20000, 20000, 25);
+            int r2 = m2.rows, k = 0;
+            const long long h0 = (long long)s.host_calls;
+            do {
+                spmv_harness_(y, m2.a, x, m2.rowstr, m2.colidx, &r2);
+                check(&m2, x, y);
+                spmv_hip_get_stats(&s);
+                ++k;
+            } while (s.uploads == 1 && k < 1000);
+            EXPECT(k == 20 && (long long)s.host_calls - h0 == 19 && s.uploads == 2);
+            spmv_hip_release(); /* both copies, before m2's arrays go */
+            free(m2.rowstr), free(m2.colidx), free(m2.a);
+            spmv_hip_get_stats(&s);
+        }
+        const long long host_before2 = (long long)s.host_calls;
         /* a tiny product still goes to the host: the PCIe round trip has not become cheaper */
         int few = 40;
         spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &few);
         spmv_hip_get_stats(&s);
-        EXPECT((long long)s.host_calls == host_before + 1);
+        EXPECT((long long)s.host_calls == host_before2 + 1);
         spmv_hip_release();
         free(m.rowstr), free(m.colidx), free(m.a), free(x), free(y);
     }
