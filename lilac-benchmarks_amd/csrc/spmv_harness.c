@@ -667,11 +667,16 @@ static void host_spmv_f32(float *ov, const float *a, const float *iv, const int 
     }
 }
 
-/* seconds: the host loop streams about a nonzero per nanosecond while the matrix fits the caches (native.c on the
- * GPU box's EPYC: 2.1 GFLOP/s on class C, out of cache) */
+/* seconds: the host loop multiplies a nonzero in about 0.35 ns while the matrix stays in the host's caches (parboil
+ * `medium`, 149 090 nonzeros: 56 us per product; NPB class W, 508 402: 0.16 ms) and in about 1 ns when it streams from
+ * memory (native.c on the GPU box's EPYC: 2.1 GFLOP/s on class C; PATHSAMPLE's 2.6 M nonzeros: 1.2 ns).  A function of
+ * the shape alone: see host_product on why the dispatch must not depend on measured time. */
+#define HOST_CACHED_BYTES ((int64_t)16 << 20)
 static double host_estimate(int rows, int64_t nnz)
 {
-    const double ns = G.calibrated && G.host_ns_per_nnz > 0.0 ? G.host_ns_per_nnz : 1.0; /* measured under =calibrated */
+    double ns = nnz * 12 <= HOST_CACHED_BYTES ? 0.35 : 1.0;
+    if (G.calibrated && G.host_ns_per_nnz > 0.0)
+        ns = G.host_ns_per_nnz; /* measured under =calibrated */
     return 1.0e-9 * ns * ((double)nnz + (double)rows) + 0.2e-6;
 }
 

@@ -95,15 +95,16 @@ static int dispatch_scenario(void)
             ++n;
         } while (s.uploads == 0 && n < 100000);
         EXPECT(s.uploads == 1 && mock_creates == 1); /* the budget ran out: the context was "created", the matrix uploaded */
-        /* the budget is charged in ESTIMATED seconds (1 ns per nonzero and row + 0.2 us), so the call that moves to the
-         * device is the same in every run on every host: 5 tiny products (1.4 us each) + n x 520.2 us < 100 ms */
-        EXPECT(s.host_calls == 5 + 192 && n == 193);
+        /* the budget is charged in ESTIMATED seconds (0.35 ns per nonzero and row of a matrix that fits the host's caches,
+         * + 0.2 us), so the call that moves to the device is the same in every run on every host: 5 tiny products
+         * (0.62 us each) + n x 182.2 us < 100 ms */
+        EXPECT(s.host_calls == 5 + 548 && n == 549);
         const long long host_before = (long long)s.host_calls;
         spmv_harness_(y, m.a, x, m.rowstr, m.colidx, &rows);
         spmv_hip_get_stats(&s);
         EXPECT((long long)s.host_calls == host_before && s.uploads == 1); /* stays on the device, cached */
         /* a second matrix of the same size, now that the context exists: on the host until it has spent what its upload
-         * costs (10 ms + 6 MB at 20 GB/s = 10.3 ms of estimated host time: 19 products of 520.2 us), then on the device */
+         * costs (10 ms + 6 MB at 20 GB/s = 10.3 ms of estimated host time: 56 products of 182.2 us), then on the device */
         {
             csr m2 = make(20000, 20000, 25);
             int r2 = m2.rows, k = 0;
@@ -114,7 +115,7 @@ static int dispatch_scenario(void)
                 spmv_hip_get_stats(&s);
                 ++k;
             } while (s.uploads == 1 && k < 1000);
-            EXPECT(k == 20 && (long long)s.host_calls - h0 == 19 && s.uploads == 2);
+            EXPECT(k == 57 && (long long)s.host_calls - h0 == 56 && s.uploads == 2);
             spmv_hip_release(); /* both copies, before m2's arrays go */
             free(m2.rowstr), free(m2.colidx), free(m2.a);
             spmv_hip_get_stats(&s);
