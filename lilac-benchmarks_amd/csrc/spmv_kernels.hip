@@ -556,6 +556,11 @@ template <typename T, int NACC> __device__ __forceinline__ void acc_add(T (&acc)
     acc[ki] = pred ? cur + v : cur;
 }
 
+/* No floating-point contraction in k_striped and k_group_sum: with every product rounded before it is added, the result
+ * is a function of the layout alone, addition by addition, and tests/striped_order.py can restate it in numpy and compare
+ * the GPU's bits with it (the vector pipe is not what bounds the kernel: class C 73.2 us with, 73.9 without the pragma,
+ * a class D row block 168.0 / 168.0; profiles/r03_striped_fp_contract_ab.log) */
+#pragma clang fp contract(off)
 template <typename T, int WPB, int R, int XT_BYTES, int EPL, int NACC, bool DIAG>
 __global__ void __launch_bounds__(WPB * 64, 4)
 k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int *__restrict__ wgd,
@@ -864,6 +869,8 @@ __global__ void __launch_bounds__(SPMV_WG) k_group_sum(const T *__restrict__ par
             dot_part[blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
     }
 }
+
+#pragma clang fp contract(fast)
 
 /* ================================ k_long ======================================== */
 template <typename T>

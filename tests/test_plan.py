@@ -464,3 +464,32 @@ def test_striped_geometry_prefers_stripes_that_divide_into_the_groups(lib):
     prod = a * x[ci - 1]
     want = np.add.reduceat(prod, rs[:-1] - 1)
     assert np.allclose(y, want, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_the_exact_order_restatement_agrees_with_the_oracle(lib, oracle, dtype):
+    """tests/striped_order.py restates k_striped's order of additions in numpy (the GPU test compares the kernel's bits with
+    it).  Here, without a GPU: it is a correct product -- within the derived STRIPED bar of the oracle -- on shapes that
+    exercise one and several stripes and groups, rows that span sub-windows, empty segments, crowded sub-windows, and it
+    differs from the plain left-to-right sum in the last bits (or the restatement would be of the wrong order)."""
+    from rowtol import STRIPED, row_tolerance
+    from striped_order import striped_exact
+    rng = np.random.default_rng(12)
+    eps = 2.0 ** -53 if dtype == np.float64 else 2.0 ** -24
+    cases = {"npb_like": matgen.npb_like(41, 3000, 200, dtype),
+             "several_stripes_and_groups": matgen.random_csr(42, 5000, 90000, 70, dtype, spread=0.4),
+             "one_entry_rows": matgen.csr_from_lengths(rng, [1] * 3000, 16000, dtype),
+             "long_rows": matgen.csr_from_lengths(rng, [3000] * 40, 20000, dtype)}
+    differs = 0
+    for name, (rs, ci, a) in cases.items():
+        rows = rs.size - 1
+        x = rng.standard_normal(int(ci.max())).astype(dtype)
+        y = striped_exact(lib, rs, ci, a, x)
+        assert y is not None, name
+        y_ref = oracle.spmv(a, x, rs, ci, rows)
+        tol = row_tolerance(np.diff(rs), oracle.absum(a, x, rs, ci, rows), eps, STRIPED, 128)
+        assert np.all(np.abs(y.astype(np.float64) - y_ref.astype(np.float64)) <= tol), name
+        differs += int(np.count_nonzero(y != y_ref))
+        if name == "one_entry_rows":
+            assert np.array_equal(y, y_ref)  # one product per row: nothing to reorder
+    assert differs > 0
