@@ -548,6 +548,37 @@ def test_host_device_dispatch(mode):
     assert (init == 0.0) == (mode == "host"), (mode, init)  # the host side never creates the HIP context
 
 
+DETERMINISM_SCRIPT = """
+import sys, hashlib
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, pkgload, matgen
+p = pkgload.load_package(); be = p.Backend()
+rs, ci, a = matgen.npb_like(81, 3000, 170)   # ~510 000 nonzeros: 0.18 ms of ESTIMATED host time per product
+rng = np.random.default_rng(81)
+h = hashlib.sha256(); y = np.empty(3000)
+for it in range(700):
+    x = rng.standard_normal(3000)
+    be.harness(y, a, x, rs, ci, 3000)
+    h.update(y.tobytes())
+s = be.stats()
+print("DET", s["calls"], s["host_calls"], s["uploads"], h.hexdigest())
+"""
+
+
+def test_the_move_from_host_to_device_happens_at_the_same_call_in_every_run():
+    """under SPMV_HIP_DISPATCH=auto a process moves from the host loop (the reference's summation order) to the
+    kernels (another order) when it has spent its budget on the host -- charged in ESTIMATED seconds, a function of the
+    shapes multiplied so far, not in measured time: two fresh processes make the move at the same call (same host_calls)
+    and produce the same bits for all 700 products, whatever the host's load was."""
+    runs = []
+    for _ in range(2):
+        out = _run_py(DETERMINISM_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__)), {"SPMV_HIP_DISPATCH": "auto"})
+        runs.append([l for l in out.splitlines() if l.startswith("DET")][0].split()[1:])
+    assert runs[0] == runs[1], runs
+    calls, host_calls, uploads, _ = runs[0]
+    assert int(calls) == 700 and 0 < int(host_calls) < 700 and int(uploads) == 1, runs[0]  # the move happened inside the run
+
+
 CLASS_D_SCRIPT = """
 import sys, time
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
@@ -596,8 +627,10 @@ def test_class_d_through_the_abi(parts):
 
 
 # ------------------------------------------------------------------ BASELINE's full size, by properties
-def test_class_c_full_size(pkg, backend, oracle):
-    """NPB class C (150000 rows, 36121058 nonzeros): the bench workload itself."""
+def test_class_c_full_size(pkg, backend, oracle, planlib):
+    """NPB class C (150000 rows, 36121058 nonzeros): the bench workload itself.  ORDERED and TILED bit-identical to the
+    oracle; STRIPED -- the headline kernel -- bit-identical to the numpy restatement of its own order of additions
+    (tests/striped_order.py) and within the derived bar of the oracle; every other plan within its bar."""
     m = pkg.npb.NpbMatrix("C")
     rows = m.na
     lens = np.diff(m.rowstr)
@@ -622,6 +655,9 @@ def test_class_c_full_size(pkg, backend, oracle):
                 assert np.array_equal(bits(y), bits(y_ref)), plan
             else:
                 assert_close_rows(y, y_ref, absum, lens, np.float64, "class C plan %d/%d" % (plan, param))
+        from striped_order import striped_exact
+        want = striped_exact(planlib, m.rowstr, m.colidx, m.a, x[: rows])
+        assert want is not None and np.array_equal(bits(results[(pkg.PLAN_STRIPED, 0)]), bits(want))
         # run-to-run reproducibility (no atomics anywhere)
         dm.set_plan(pkg.PLAN_AUTO, 0)
         assert np.array_equal(bits(dm.spmv_host(x)), bits(results[(pkg.PLAN_AUTO, 0)]))
