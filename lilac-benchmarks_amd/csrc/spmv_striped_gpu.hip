@@ -258,6 +258,8 @@ extern "C" int spmv_striped_build_device(const int *d_rowptr, const int *d_col, 
         return -2;
     if (S > SG_MAX_STRIPES || NG > 64 || nnz <= 0)
         return -4;
+    if ((int64_t)rows * S * 6 > ((int64_t)16 << 30)) /* the per-(row, stripe) temporaries would not be small beside the matrix */
+        return -4;
     unsigned short *d_cnt = nullptr, *d_tcol = nullptr;
     unsigned int *d_off = nullptr, *d_wgt = nullptr;
     int *d_flags = nullptr, *d_gs0 = nullptr, *d_ubase = nullptr, *d_rrow = nullptr, *d_wgd = nullptr, *d_tptr = nullptr;
