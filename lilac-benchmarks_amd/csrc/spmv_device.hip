@@ -32,6 +32,8 @@
 
 extern "C" void spmvk_set_tuning(int key, int value);
 extern "C" void spmvk_blocked_set_wgs(int per_xcd);
+extern "C" int spmvk_get_tuning_xcd(void);
+static bool g_tune_xcd_enabled() { return spmvk_get_tuning_xcd() != 0; }
 
 namespace {
 
@@ -507,6 +509,7 @@ extern "C" void spmvd_set_relayout(int on) { g_relayout = on ? 1 : 0; }
 /* geometry knobs of the STRIPED plan (experiments through spmv_hip_set_tuning keys 9, 11, 12, 15); read by the upload
  * threads of a row partition side by side, so atomics; set them only while no upload is in flight */
 static std::atomic<int> g_stripe_wgs{0}, g_stripe_groups{0}, g_stripe_wave_rows{SPMV_STRIPE_WAVE_ROWS}, g_stripe_shape{0};
+static std::atomic<int> g_stripe_xcd_bias{SPMV_STRIPE_XCD_BIAS};
 
 /* Builds the STRIPED layout; same conventions as ensure_tiled.  The conversion runs on the GPU, from the CSR copy that
  * is already in HBM (spmv_striped_gpu.hip), unless the matrix is not a case for it (rows not sorted by column, more than
@@ -540,6 +543,7 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
         so.target_wgs = g_stripe_wgs.load();
     so.groups = g_stripe_groups.load();
     so.wave_rows = g_stripe_wave_rows.load();
+    so.xcd_bias = g_tune_xcd_enabled() ? g_stripe_xcd_bias.load() : 0;
 
     void *d_c = nullptr, *d_v = nullptr; /* the packed arrays, when the device built them */
     int rc = -4;
@@ -1403,6 +1407,8 @@ void spmv_hip_set_tuning(int key, int value)
         g_stripe_groups = value;
     else if (key == 12 && value >= 64 && value <= SPMV_STRIPE_WAVE_ROWS && value % 64 == 0)
         g_stripe_wave_rows = value;
+    else if (key == 19 && value >= -200 && value <= 200)
+        g_stripe_xcd_bias = value; /* STRIPED: per mille of weight moved from even-XCD workgroups to odd-XCD ones */
     else if (key == 18)
         spmvk_blocked_set_wgs(value); /* BLOCKED phase 1: workgroups per XCD */
     else if (key == 17 && value >= 0 && value <= 2)

@@ -129,6 +129,7 @@ void spmv_tiled_set_blocks(int blocks); /* experiments: workgroups aimed for (0 
 #define SPMV_STRIPE_TARGET_WGS 256 /* workgroups aimed for: one 160-KiB workgroup per CU          */
 #define SPMV_STRIPE2_XBYTES 65536  /* the half-width shape: 64 KiB of x, 8 waves, two workgroups per CU (2 x 80 KiB of LDS) */
 #define SPMV_STRIPE2_WPB 8
+#define SPMV_STRIPE_XCD_BIAS 0     /* per mille of weight moved from even-XCD workgroups to odd-XCD ones (tuning key 19) */
 #define SPMV_STRIPE_EPL 4          /* entries per lane per sub-window                            */
 #define SPMV_STRIPE_NACC 16        /* row accumulators per lane                                   */
 #define SPMV_STRIPE_WAVE_ROWS (64 * SPMV_STRIPE_NACC) /* rows a wave can carry across a stripe group */
@@ -138,6 +139,7 @@ typedef struct spmv_striped_opts {
     int target_wgs; /* workgroups aimed for (NB * NG)                                */
     int wave_rows;  /* most rows per wave range (a multiple of 64)                   */
     int groups;     /* stripe groups, 0 = choose                                     */
+    int xcd_bias;   /* per mille of weight moved from the workgroups of even XCDs to those of odd ones (0 = none) */
     int stripes;    /* column stripes, 0 = choose (the fewest that fit the LDS buffer, or a few more so that
                        they divide into the groups)                                  */
 } spmv_striped_opts;

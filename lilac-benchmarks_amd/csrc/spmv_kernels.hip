@@ -1073,6 +1073,8 @@ void launch_striped_shape(const spmv_dev_striped *t, const void *x, void *y, hip
 
 extern "C" {
 
+int spmvk_get_tuning_xcd(void) { return g_tune_xcd; }
+
 void spmvk_set_tuning(int key, int value)
 {
     if (key == 0)

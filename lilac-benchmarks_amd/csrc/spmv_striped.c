@@ -72,6 +72,7 @@ void spmv_striped_default_opts(spmv_striped_opts *o)
     o->wave_rows = SPMV_STRIPE_WAVE_ROWS;
     o->groups = 0;
     o->stripes = 0;
+    o->xcd_bias = 0;
 }
 
 int spmv_striped_choose_shape(const spmv_row_stats *st, int elem_size, int cols)
@@ -351,15 +352,21 @@ static void pass_scatter(int64_t lo, int64_t hi, void *vc)
  * The wave ranges of one group: n runs of consecutive rows of about equal weight (the group's entries per row),
  * none longer than wave_rows rows, every one non-empty while rows last.  rr[2 i], rr[2 i + 1] = first / end row.
  */
-static void cut_rows(const uint32_t *wgt, int rows, int n, int wave_rows, int32_t *rr)
+/* share[i] (per mille, NULL = all equal): the part of the weight range i should get relative to the others -- the ranges
+ * of workgroups that run on a slower XCD get a little less (spmv_striped_cut_all) */
+static void cut_rows(const uint32_t *wgt, int rows, int n, int wave_rows, const int *share, int32_t *rr)
 {
-    int64_t remaining = 0;
+    int64_t remaining = 0, share_left = 0;
     for (int r = 0; r < rows; ++r)
         remaining += wgt[r];
+    for (int i = 0; i < n; ++i)
+        share_left += share ? share[i] : 1000;
     int r = 0;
     for (int i = 0; i < n; ++i) {
         const int first = r, left = n - i;
-        const int64_t target = (remaining + left - 1) / left;
+        const int64_t mine = share ? share[i] : 1000;
+        const int64_t target = share_left > 0 ? (remaining * mine + share_left - 1) / share_left : 0;
+        share_left -= mine;
         int64_t acc = 0;
         while (r < rows) {
             const int64_t w = wgt[r];
@@ -534,9 +541,24 @@ void spmv_striped_alloc_blocks(const spmv_striped_opts *opts, int rows, const in
 void spmv_striped_cut_all(const spmv_striped_opts *opts, int rows, const uint32_t *wgt, const int *gnb, spmv_striped_host *t)
 {
     const int NG = t->NG, S = t->S, WPB = t->WPB;
+    /*
+     * XCD bias (opts->xcd_bias, per mille; 0 = none).  The launcher hands workgroups [i * per, (i + 1) * per), per =
+     * ceil(n_wg / 8), to XCD i (xcd_contiguous in spmv_kernels.hip), and on every MI355X measured in rounds 2 and 3 the
+     * workgroups of XCDs 0, 2, 4, 6 end 2-4 % later than those of XCDs 1, 3, 5, 7 whatever they hold (tools/wgtimes.py).
+     * With a bias b the wave ranges of workgroups on even XCDs get (1000 - b) / 1000 of an equal share of their group's
+     * weight and those on odd XCDs (1000 + b) / 1000.
+     */
+    const int per = (t->n_wg + 7) / 8;
+    int *share = NULL;
+    if (opts->xcd_bias != 0 && t->n_wg >= 16) {
+        share = (int *)malloc((size_t)t->NB * WPB * sizeof(int));
+    }
     int q = 0;
     for (int g = 0; g < NG; ++g) {
-        cut_rows(wgt + (size_t)g * rows, rows, gnb[g] * WPB, opts->wave_rows, t->rrow + (size_t)q * WPB * 2);
+        if (share)
+            for (int i = 0; i < gnb[g] * WPB; ++i)
+                share[i] = 1000 + ((((q + i / WPB) / per) & 1) ? opts->xcd_bias : -opts->xcd_bias);
+        cut_rows(wgt + (size_t)g * rows, rows, gnb[g] * WPB, opts->wave_rows, share, t->rrow + (size_t)q * WPB * 2);
         for (int rb = 0; rb < gnb[g]; ++rb, ++q) {
             t->wgd[4 * q + 0] = (int)((int64_t)g * S / NG);
             t->wgd[4 * q + 1] = (int)((int64_t)(g + 1) * S / NG);
@@ -544,6 +566,7 @@ void spmv_striped_cut_all(const spmv_striped_opts *opts, int rows, const uint32_
             t->wgd[4 * q + 3] = rb;
         }
     }
+    free(share);
 }
 
 /*

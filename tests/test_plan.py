@@ -238,14 +238,14 @@ class StripedHost(ctypes.Structure):
 
 class StripedOpts(ctypes.Structure):
     _fields_ = [("xbytes", ctypes.c_int), ("wpb", ctypes.c_int), ("target_wgs", ctypes.c_int),
-                ("wave_rows", ctypes.c_int), ("groups", ctypes.c_int), ("stripes", ctypes.c_int)]
+                ("wave_rows", ctypes.c_int), ("groups", ctypes.c_int), ("xcd_bias", ctypes.c_int), ("stripes", ctypes.c_int)]
 
 
 def striped_build(lib, rs, ci, a, xbytes=65536, wpb=8, wgs=6, wave_rows=128, groups=0):
     rows = rs.size - 1
     cols = int(ci.max()) if ci.size else 0
     t = StripedHost()
-    o = StripedOpts(xbytes, wpb, wgs, wave_rows, groups, 0)
+    o = StripedOpts(xbytes, wpb, wgs, wave_rows, groups, 0, 0)
     lib.spmv_striped_build.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.POINTER(StripedOpts), ctypes.POINTER(StripedHost)]
     rc = lib.spmv_striped_build(a.ctypes.data, rs.ctypes.data, ci.ctypes.data, 0, rows, cols, a.dtype.itemsize,

@@ -5,7 +5,7 @@ drift by a few per cent within a run).  GPU box only.
 
     python tools/shapebench.py --cases D/8,D/4,C --configs 1:0:0,2:0:0,2:0:768 --rounds 8
 
-A configuration is shape:groups:workgroups (0 = the builder's choice); shape 1 = 16 waves x 128 KiB of x (one workgroup
+A configuration is shape:groups:workgroups[:xcd_bias] (0 = the builder's choice; xcd_bias in per mille); shape 1 = 16 waves x 128 KiB of x (one workgroup
 per CU), 2 = 8 waves x 64 KiB (two per CU).
 """
 import argparse
@@ -51,23 +51,26 @@ def main():
         ref.close()
         print("# %s: rows=%d cols=%d nnz=%d alg_bytes=%d" % (case, rows, inf["cols"], inf["nnz"], inf["algorithmic_bytes"]), flush=True)
         mats = []
-        for shape, ng, wgs in cfgs:
+        for cfg in cfgs:
+            shape, ng, wgs = cfg[:3]
+            bias = cfg[3] if len(cfg) > 3 else 0
             be.set_tuning(15, shape)
             be.set_tuning(11, ng)
             be.set_tuning(9, wgs)
+            be.set_tuning(19, bias)  # per mille of weight moved from even-XCD workgroups to odd-XCD ones
             dm = be.matrix(a, rs, ci, rows, cols_hint=hint)
             try:
                 dm.set_plan(pkg.PLAN_STRIPED, 0)
             except RuntimeError as e:
-                print("%-6s %d:%d:%d unavailable: %s" % (case, shape, ng, wgs, e), flush=True)
+                print("%-6s %s unavailable: %s" % (case, cfg, e), flush=True)
                 dm.close()
                 continue
             dm.spmv_device(dx, dy)
             y = be.d2h(np.empty(rows, dtype), dy)
             err = float(np.max(np.abs(y - y_ref)) / max(1e-300, float(np.max(np.abs(y_ref)))))
             dm.time_device(dx, dy, 30)
-            mats.append(((shape, ng, wgs), dm, dm.info(), err))
-        be.set_tuning(15, 0), be.set_tuning(11, 0), be.set_tuning(9, 0)
+            mats.append(((shape, ng, wgs, bias), dm, dm.info(), err))
+        be.set_tuning(15, 0), be.set_tuning(11, 0), be.set_tuning(9, 0), be.set_tuning(19, 0)
         acc = {k: [] for k, *_ in mats}
         for _ in range(args.rounds):
             for k, dm, _, _ in mats:
@@ -75,8 +78,8 @@ def main():
                 acc[k].append(dm.time_device(dx, dy, args.reps) / args.reps * 1e3)
         for k, dm, i2, err in mats:
             v = np.array(acc[k])
-            print("%-6s shape=%d groups=%d wgs=%d -> workgroups=%d launches=%d  mean %.2f us  median %.2f  min %.2f  std %.2f   %.1f GB/s(alg) frac %.3f  max|dy|/max|y| %.1e" % (
-                case, k[0], k[1], k[2], i2["n_blocks"], i2["n_launches"], v.mean(), np.median(v), v.min(), v.std(),
+            print("%-6s shape=%d groups=%d wgs=%d xcd_bias=%d -> workgroups=%d launches=%d  mean %.2f us  median %.2f  min %.2f  std %.2f   %.1f GB/s(alg) frac %.3f  max|dy|/max|y| %.1e" % (
+                case, k[0], k[1], k[2], k[3], i2["n_blocks"], i2["n_launches"], v.mean(), np.median(v), v.min(), v.std(),
                 i2["algorithmic_bytes"] / np.median(v) / 1e3, i2["algorithmic_bytes"] / np.median(v) / 1e3 / 8000.0, err), flush=True)
             dm.close()
         be.free(dx)
