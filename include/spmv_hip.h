@@ -179,7 +179,8 @@ int spmv_hip_synchronize(int device);
  * stripe groups, most rows per wave range; 0 = choose); 15 STRIPED kernel shape (0 = chosen per matrix, 1 = 16 waves x
  * 128 KiB of x, 2 = 8 waves x 64 KiB); 17 who converts to STRIPED (0 = the GPU, from the CSR copy in HBM, the host threads
  * when it must; 1 = the host; 2 = the GPU or fail); 18 BLOCKED phase-1 workgroups per XCD; 19 STRIPED: per mille of weight
- * moved from the workgroups of even XCDs to those of odd ones (default 0: measured, within noise).  Diagnostics (ablation bits, clock stamps, fault injection) are not in this
+ * moved from the workgroups of even XCDs to those of odd ones (default 0: measured, within noise); 20 STRIPED: the packed
+ * stream is loaded non-temporally 0 = when it exceeds the Infinity Cache, 1 = always, 2 = never.  Diagnostics (ablation bits, clock stamps, fault injection) are not in this
  * library: they live in the debug build, include/spmv_hip_debug.h. */
 void spmv_hip_set_tuning(int key, int value);
 

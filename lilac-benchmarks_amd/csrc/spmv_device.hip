@@ -681,6 +681,7 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
     m->ds.xbytes = so.xbytes; /* with WPB: which of the two kernel shapes */
     m->ds.rows = m->rows;
     m->ds.cols = m->cols;
+    m->ds.n_packed = th.n_packed;
     m->striped_bytes = ntp * 4 + ((size_t)th.n_ranges * 2 + 2) * 4 + ((size_t)th.n_wg * 4 + 4) * 4 + n_alloc * (2 + (size_t)m->elem) + pbytes;
     m->device_bytes += m->striped_bytes;
     m->have_striped = true;

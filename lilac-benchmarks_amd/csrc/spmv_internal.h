@@ -129,6 +129,7 @@ void spmv_tiled_set_blocks(int blocks); /* experiments: workgroups aimed for (0 
 #define SPMV_STRIPE_TARGET_WGS 256 /* workgroups aimed for: one 160-KiB workgroup per CU          */
 #define SPMV_STRIPE2_XBYTES 65536  /* the half-width shape: 64 KiB of x, 8 waves, two workgroups per CU (2 x 80 KiB of LDS) */
 #define SPMV_STRIPE2_WPB 8
+#define SPMV_STRIPE_NT_BYTES (320ll << 20) /* a packed stream well beyond the 256-MB Infinity Cache is loaded non-temporally (crossover measured between 300 and 360 MB: profiles/r03_striped_nt_by_stream_size.log) */
 #define SPMV_STRIPE_XCD_BIAS 0     /* per mille of weight moved from even-XCD workgroups to odd-XCD ones (tuning key 19) */
 #define SPMV_STRIPE_EPL 4          /* entries per lane per sub-window                            */
 #define SPMV_STRIPE_NACC 16        /* row accumulators per lane                                   */
@@ -217,6 +218,7 @@ typedef struct spmv_dev_striped {
     void *partial;          /* T[NG * rows], NULL when NG == 1 */
     int elem, W, S, WPB, NB, NG, GM, EPL, n_wg, n_ranges, wave_rows, rows, cols;
     int xbytes; /* LDS stripe capacity the layout was built for */
+    int64_t n_packed; /* entries of the packed stream, pads included */
 } spmv_dev_striped;
 /* BLOCKED (spmv_blocked.hip): entries block-major (column blocks of SPMV_BLOCKED_XBYTES of x), one sum per (row, block)
  * segment, one row mask per (block, 64-row group) cell */

@@ -49,6 +49,7 @@ namespace {
 /* ---- tuning switches (set through spmvk_set_tuning; experiments only) ------- */
 int g_tune_xcd = 1;     /* give each XCD a contiguous range of row blocks        */
 int g_tune_nt = 0;      /* non-temporal loads for the streamed a / colidx        */
+int g_tune_striped_nt = 0; /* k_striped's packed stream: 0 non-temporal loads when it exceeds the Infinity Cache, 1 always, 2 never */
 int g_tune_tile_k = 0;  /* register sets of k_tiled (2,4,6,8; default 4); debug build: of k_striped too (2,3,4; default 2) */
 #ifdef SPMV_HIP_DEBUG_BUILD
 /* The instrumented twin of k_striped (template parameter DIAG) exists in the debug build only (make debug ->
@@ -530,7 +531,12 @@ template <typename T, int EPL> struct StripeRegs {
     }
 };
 
-template <typename T, int EPL>
+/* NT: non-temporal loads.  A packed stream larger than the 256-MB Infinity Cache is read once per product and never found
+ * there again; loading it without allocating leaves the cache to x and the partial sums and the memory system to stream:
+ * class C 73.7 -> 71.0 us, a class D row block 172.0 -> 156.6, half of class D 605 -> 559 (profiles/r03_striped_nt_ab.log).
+ * A stream that FITS the cache (class B: 138 MB) is served from it on every product after the first, and non-temporal
+ * loads forfeit that: 28.1 -> 31.2 us.  The launcher decides by the stream's size. */
+template <typename T, int EPL, bool NT>
 __device__ __forceinline__ void stripe_load(StripeRegs<T, EPL> &r, const T *__restrict__ pval,
                                             const unsigned short *__restrict__ pcol, int sb, int lane)
 {
@@ -538,11 +544,11 @@ __device__ __forceinline__ void stripe_load(StripeRegs<T, EPL> &r, const T *__re
     constexpr int E = Vec16<T>::E;
     const unsigned int base = (unsigned int)sb;
     static_assert(EPL == 4, "one 8-byte column load per lane");
-    const u32x2 cc = *reinterpret_cast<const u32x2 *>(pcol + base + (unsigned int)lane * 4u);
+    const u32x2 cc = ld<u32x2, NT>(reinterpret_cast<const u32x2 *>(pcol + base + (unsigned int)lane * 4u));
     r.c[0] = cc[0], r.c[1] = cc[1];
 #pragma unroll
     for (int j = 0; j < StripeRegs<T, EPL>::NV; ++j)
-        r.v[j] = *reinterpret_cast<const VT *>(pval + base + (unsigned int)(j * 64 * E) + (unsigned int)lane * E);
+        r.v[j] = ld<VT, NT>(reinterpret_cast<const VT *>(pval + base + (unsigned int)(j * 64 * E) + (unsigned int)lane * E));
 }
 
 /* acc[k] += v in the lanes where pred holds.  k is wave-uniform (made so with readfirstlane), which lets the
@@ -561,7 +567,7 @@ template <typename T, int NACC> __device__ __forceinline__ void acc_add(T (&acc)
  * the GPU's bits with it (the vector pipe is not what bounds the kernel: class C 73.2 us with, 73.9 without the pragma,
  * a class D row block 168.0 / 168.0; profiles/r03_striped_fp_contract_ab.log) */
 #pragma clang fp contract(off)
-template <typename T, int WPB, int R, int XT_BYTES, int EPL, int NACC, bool DIAG>
+template <typename T, int WPB, int R, int XT_BYTES, int EPL, int NACC, bool DIAG, bool NTLOAD>
 __global__ void __launch_bounds__(WPB * 64, 4)
 k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int *__restrict__ wgd,
           const unsigned short *__restrict__ pcol, const T *__restrict__ pval, const T *__restrict__ x,
@@ -607,7 +613,7 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
     StripeRegs<T, EPL> set[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        stripe_load<T, EPL>(set[r], pval, pcol, P + r * SUB, lane);
+        stripe_load<T, EPL, NTLOAD>(set[r], pval, pcol, P + r * SUB, lane);
 
     /* per-stripe state of the wave */
     unsigned int row = 0, flushed = 0; /* local row numbers: next row to end, first row still in the ring */
@@ -637,7 +643,7 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
             p[k] = regs.val(k) * s_x[c & (W - 1)];
             f[k] = (int)(c >> 15);
         }
-        stripe_load<T, EPL>(regs, pval, pcol, sb + R * SUB, lane); /* may run into the wave's next tile: same stream */
+        stripe_load<T, EPL, NTLOAD>(regs, pval, pcol, sb + R * SUB, lane); /* may run into the wave's next tile: same stream */
         /* lane-local: the sum after the lane's last row end, and whether it has a row end */
         T tailv = (T)0;
         int has = 0;
@@ -1046,9 +1052,17 @@ template <typename T, int WPB, int XB, int R, bool DIAG>
 void launch_striped(const spmv_dev_striped *t, const void *x, void *y, hipStream_t st, const void *dotv,
                            void *dot_part, int grid, int nwg, int per, int abl)
 {
-    hipLaunchKernelGGL((k_striped<T, WPB, R, XB, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC, DIAG>), dim3(grid), dim3(WPB * 64), 0,
-                       st, t->tptr, t->rrow, t->wgd, t->col, (const T *)t->val, (const T *)x, (T *)y, (T *)t->partial,
-                       (const T *)dotv, (T *)dot_part, t->rows, t->cols, t->NG, t->GM, t->W, nwg, per, abl);
+    /* non-temporal loads of the packed stream when it cannot stay in the Infinity Cache anyway (see stripe_load) */
+    const long long stream = (long long)t->n_packed * (long long)(sizeof(T) + 2);
+    const bool nt = g_tune_striped_nt == 1 || (g_tune_striped_nt == 0 && stream > SPMV_STRIPE_NT_BYTES);
+    if (nt)
+        hipLaunchKernelGGL((k_striped<T, WPB, R, XB, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC, DIAG, true>), dim3(grid), dim3(WPB * 64), 0,
+                           st, t->tptr, t->rrow, t->wgd, t->col, (const T *)t->val, (const T *)x, (T *)y, (T *)t->partial,
+                           (const T *)dotv, (T *)dot_part, t->rows, t->cols, t->NG, t->GM, t->W, nwg, per, abl);
+    else
+        hipLaunchKernelGGL((k_striped<T, WPB, R, XB, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC, DIAG, false>), dim3(grid), dim3(WPB * 64), 0,
+                           st, t->tptr, t->rrow, t->wgd, t->col, (const T *)t->val, (const T *)x, (T *)y, (T *)t->partial,
+                           (const T *)dotv, (T *)dot_part, t->rows, t->cols, t->NG, t->GM, t->W, nwg, per, abl);
 }
 
 template <typename T, int WPB, int XB>
@@ -1083,6 +1097,8 @@ void spmvk_set_tuning(int key, int value)
         g_tune_nt = value;
     else if (key == 5 && value >= 0 && value <= 8)
         g_tune_tile_k = value;
+    else if (key == 20 && value >= 0 && value <= 2)
+        g_tune_striped_nt = value;
 #ifdef SPMV_HIP_DEBUG_BUILD
     else if (key == 6)
         g_tune_abl = value;
