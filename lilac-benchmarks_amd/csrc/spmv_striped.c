@@ -390,10 +390,13 @@ static void cut_rows(const uint32_t *wgt, int rows, int n, int wave_rows, const 
 }
 
 /*
- * How many stripe groups, and how many stripes?  A workgroup's time is modelled as stripes x (its waves' tile, rounded up
- * to whole sub-windows, + RESTAGE entries for the change of stripe: two barriers and the stripe of x cost a wave about
- * what 400-500 entries do -- 2.1 us per stripe on a class D row block, profiles/r03_wgtimes.log) plus its share of the
- * partial sums (written once and read once per group and row); the launch lasts as long as its most expensive workgroup.
+ * How many stripe groups, and how many stripes?  A workgroup's time is modelled as stripes x (its waves' tile, + half a
+ * sub-window of padding, + RESTAGE entries for the change of stripe) plus its share of the partial sums; the launch lasts
+ * as long as its most expensive workgroup.  The two constants are fitted to the kernel as it stands since the packed
+ * stream is loaded non-temporally (class C with 10 / 8 / 5 / 4 / 2 groups, four allocations each: 69.8 / 66.8 / 67.1 /
+ * 65.8 / 69.1 us, profiles/r03_shapebench_groups_after_nt.log: 1.5 us per stripe staged, 0.84 us per group -- its partial
+ * sums are written, read again and added by a second launch); before, a stripe cost twice that and class C ran best with
+ * one stripe per workgroup.
  *
  * S stripes rarely divide into the groups: groups of ceil(S/ng) and of floor(S/ng) stripes get row blocks in proportion
  * to their stripes, never fewer than nb_min (the accumulators: a wave carries wave_rows rows at most), and all blocks
@@ -406,7 +409,8 @@ static void cut_rows(const uint32_t *wgt, int rows, int n, int wave_rows, const 
  * the cheapest most expensive workgroup wins, the larger group count on a tie.  Class C: 10 groups of 1 stripe (25-26 row
  * blocks each); all of class D: 2 groups of 46 stripes.
  */
-#define STRIPE_RESTAGE_ENTRIES 512
+#define STRIPE_RESTAGE_ENTRIES 256 /* a change of stripe, in entries of a wave's stream (1.5 us at 174 entries per us) */
+#define STRIPE_PARTIAL_FACTOR 2.5  /* a group's partial sums cost 2.5 x their bytes: k_group_sum's own time is in it */
 static double geometry_cost(int S, int cand, int nb_min, int target, int wpb, int64_t nnz, int64_t sub, int rows, int elem)
 {
     const double per_stripe = (double)nnz / (double)S;
@@ -429,12 +433,12 @@ static double geometry_cost(int S, int cand, int nb_min, int target, int wpb, in
         if (n == 0)
             continue;
         const double tile = per_stripe / ((double)nb * wpb);
-        const double padded = (double)(((int64_t)tile + sub - 1) / sub * sub);
+        const double padded = tile + 0.5 * (double)sub; /* a tile ends somewhere inside its last sub-window */
         const double c = st * (padded + STRIPE_RESTAGE_ENTRIES);
         cost = c > cost ? c : cost;
     }
-    if (cand > 1) /* the partial sums, in entries (elem + 2 bytes each), per wave */
-        cost += (double)cand * rows * 2.0 * elem / (elem + 2.0) / ((double)target * wpb);
+    if (cand > 1) /* the partial sums, in entries (elem + 2 bytes each), per wave; written, read again, and added by a second launch */
+        cost += STRIPE_PARTIAL_FACTOR * (double)cand * rows * 2.0 * elem / (elem + 2.0) / ((double)target * wpb);
     return cost;
 }
 

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--allocs", type=int, default=1, help="matrix objects per configuration (two allocations of one layout differ by up to 4 %)")
     args = ap.parse_args()
     pkg = pkgload.load_package()
     be = pkg.Backend()
@@ -51,7 +52,7 @@ def main():
         ref.close()
         print("# %s: rows=%d cols=%d nnz=%d alg_bytes=%d" % (case, rows, inf["cols"], inf["nnz"], inf["algorithmic_bytes"]), flush=True)
         mats = []
-        for cfg in cfgs:
+        for cfg in [c for c in cfgs for _ in range(args.allocs)]:
             shape, ng, wgs = cfg[:3]
             bias = cfg[3] if len(cfg) > 3 else 0
             be.set_tuning(15, shape)
@@ -69,13 +70,20 @@ def main():
             y = be.d2h(np.empty(rows, dtype), dy)
             err = float(np.max(np.abs(y - y_ref)) / max(1e-300, float(np.max(np.abs(y_ref)))))
             dm.time_device(dx, dy, 30)
-            mats.append(((shape, ng, wgs, bias), dm, dm.info(), err))
+            mats.append(((shape, ng, wgs, bias, len(mats)), dm, dm.info(), err))
         be.set_tuning(15, 0), be.set_tuning(11, 0), be.set_tuning(9, 0), be.set_tuning(19, 0)
         acc = {k: [] for k, *_ in mats}
         for _ in range(args.rounds):
             for k, dm, _, _ in mats:
                 dm.time_device(dx, dy, 2)
                 acc[k].append(dm.time_device(dx, dy, args.reps) / args.reps * 1e3)
+        if args.allocs > 1:  # per configuration over its allocations
+            for cfg in cfgs:
+                key = tuple(cfg[:3]) + ((cfg[3] if len(cfg) > 3 else 0),)
+                vs = [np.median(acc[k]) for k, *_ in mats if k[:4] == key]
+                if vs:
+                    print("%-6s shape=%d groups=%d wgs=%d xcd_bias=%d: medians of %d allocations %s  -> mean %.2f us" % (
+                        (case,) + key + (len(vs), " ".join("%.2f" % v for v in vs), float(np.mean(vs)))), flush=True)
         for k, dm, i2, err in mats:
             v = np.array(acc[k])
             print("%-6s shape=%d groups=%d wgs=%d xcd_bias=%d -> workgroups=%d launches=%d  mean %.2f us  median %.2f  min %.2f  std %.2f   %.1f GB/s(alg) frac %.3f  max|dy|/max|y| %.1e" % (
