@@ -406,7 +406,7 @@ static void cut_rows(const uint32_t *wgt, int rows, int n, int wave_rows, const 
  * ended 14 us after the latter (151.5 against 137.9 us of a 161-us launch).  So besides the fewest stripes that fit the
  * LDS buffer, every group count is also tried with the next multiple of itself as the number of (slightly narrower)
  * stripes: 16 groups x 6 stripes x 16 row blocks = 256 equal workgroups for that block.  Of all candidates the one with
- * the cheapest most expensive workgroup wins, the larger group count on a tie.  Class C: 10 groups of 1 stripe (25-26 row
+ * the cheapest most expensive workgroup wins, the larger group count on a tie.  Class C: 5 groups of 2 stripes (51-52 row
  * blocks each); all of class D: 2 groups of 46 stripes.
  */
 #define STRIPE_RESTAGE_ENTRIES 256 /* a change of stripe, in entries of a wave's stream (1.5 us at 174 entries per us) */
