@@ -30,10 +30,12 @@
  *               LDS; one lane per row adds in stored order (bit-exact on sorted
  *               columns).  Layout: spmv_tiled.c.
  *   k_striped   2-D decomposition: a workgroup = (group of column stripes, row block) keeps a
- *               stripe of x in LDS, streams packed (value, 16-bit column) entries and
- *               carries row sums in registers across the stripes of its group; the last
- *               wave to deliver a row range's partial sums adds them up (one launch).
- *               Layout: spmv_striped.c.  The NPB class B/C/D kernel.
+ *               stripe of x in LDS, streams packed (value, 16-bit column) entries -- with
+ *               non-temporal loads when the stream cannot stay in the Infinity Cache anyway --
+ *               and carries row sums in registers across the stripes of its group; k_group_sum
+ *               adds the groups' partial sums in group order (a second, small launch).
+ *               Layout: spmv_striped.c, built on the GPU by spmv_striped_gpu.hip.  The NPB
+ *               class B/C/D kernel; no FP contraction: bit-identical to tests/striped_order.py.
  *
  * Column ids stay 1-based as the ABI delivers them; kernels index x through
  * (x - 1).  a/colidx are over-allocated by SPMV_PAD_ELEMS entries (a = 0,
