@@ -1,28 +1,37 @@
 /*
- * csrc/spmv_blocked.hip -- the BLOCKED plan: column-blocked y = A*x for matrices whose x does not fit a cache that
- * gathers well and whose rows are too short per stripe for STRIPED (SparseBench's crsmat170u: 4.9 M rows of ~5 uniformly
- * scattered nonzeros, x = 39 MB).
+ * csrc/spmv_blocked.hip -- the BLOCKED plan: a two-phase y = A*x over (column stripe, row bin) cells, for matrices whose x
+ * is far larger than a cache that gathers well and whose rows are too short per stripe for STRIPED (SparseBench's
+ * crsmat170u: 4.9 M rows of ~5 uniformly scattered nonzeros, x = 39 MB).
  *
  * The CSR kernels gather x wherever the columns point; when x is ten times an XCD's L2, every gather misses it and
  * fetches a 64-byte line across the fabric for 8 bytes (profiles/traffic.json, sb170/stream: 1.55 GB of fabric reads for
- * 24 M gathers, 4-8 x the algorithmic bytes; 431 us).  Here the entries are re-ordered BLOCK-MAJOR -- column block c =
- * columns [c * CB, (c + 1) * CB), 2 MB of x, inside a block row after row, inside a row in CSR order -- and XCD c % 8 works
- * on block c: everything an XCD gathers at one time comes out of one x block that fits its 4-MB L2.
+ * 24 M gathers, 4-8 x the algorithmic bytes; 370 us).  STRIPED's answer -- x in LDS, stripe by stripe -- needs every row
+ * to have entries in most stripes.  Here NOTHING gathers from memory and nothing is written in pieces smaller than a
+ * (stripe, bin) cell:
  *
- *   k_blk_sums   phase 1: waves stream units of ~2048 entries of their XCD's blocks (value, column with the "last entry
- *                of its (row, block) segment" flag in bit 31), multiply by x, and sum every segment with the segmented
- *                wave scan of k_striped (DPP; a carry joins the groups of 64 a segment spans); segment sums go to a
- *                compact array, one per segment, in stream order
- *   k_blk_rows   phase 2: a wave per 64 rows; lane l adds the segment sums of row 64 g + l, block after block: which
- *                rows of the group have a segment in a block is one 64-bit mask per (block, row group), so a lane finds
- *                its sum by counting bits -- no per-row index lists
+ *   k_blk_products  phase 1.  The entries are stored in (column stripe, row bin, row) order.  A workgroup keeps ITS stripe
+ *                   of x in LDS (up to 160 KB: 256 stripes cover 5.2 M columns of doubles, one per CU), streams packed
+ *                   (value, 16-bit stripe-local column) entries, multiplies, and writes the PRODUCTS to where phase 2
+ *                   wants them.  Both orders keep a cell contiguous and in the same inner order, so one 4-byte
+ *                   destination per FOUR products says where they go (cells are padded to multiples of four).
+ *   k_blk_bins      phase 2.  The products in (row bin, column stripe, row) order, next to a 16-bit bin-local row each.  ONE
+ *                   wave per bin of 2048 rows streams them and adds every product to its row's sum in the wave's slice of
+ *                   LDS (ds_add: the slice belongs to that wave alone), then writes the slice to y.
  *
- * Deterministic (fixed trees, fixed block order, no atomics on the data path), not the reference's left-to-right order:
- * parity is the CSR bar of tests/rowtol.py.  One product in flight per matrix (the segment sums are scratch).
+ * Every array is read as a linear stream (the first round-3 version of this plan gathered x from L2, column block by
+ * column block: 422 us on crsmat170u against 371 for STREAM; this one: DESIGN.md 4.7).  The products cross memory once
+ * more than in a CSR kernel (8 B written, 8 + 2 B read per entry): the plan pays off only where the gathers cost more
+ * than that, which the automatic choice checks (spmv_plan.c).
  *
- * The layout is built ON THE DEVICE from the CSR copy (k_bk_cells, a scan, k_bk_scatter).  With up to 64 column blocks
- * (x up to 128 MB) the rows' columns may come in any order; beyond that rows must be sorted by column (then a
- * (row, block) segment is one run of the row).
+ * Order of the additions: a row's products are added in the order of the stream (stripe after stripe), 256 entries per
+ * step, four instructions of 64 lanes each.  Two lanes of ONE instruction that hold products of the same row are added by
+ * the LDS in its own fixed order for a given address pattern -- there is no other wave on these addresses and a wave's
+ * LDS operations complete in order --, so the result is a function of the layout (tests compare fresh processes bit for
+ * bit), but unlike STRIPED's it is not an order this file can write down.  Not the reference's left-to-right order: parity
+ * is the CSR bar of tests/rowtol.py.  One product in flight per matrix (the products are scratch).
+ *
+ * The layout is built ON THE DEVICE from the CSR copy (k_bb_count, host prefix sums over the cells, k_bb_scatter,
+ * k_bb_dest); rows may hold their columns in any order.
  */
 #include <hip/hip_runtime.h>
 
@@ -34,8 +43,9 @@
 
 namespace {
 
-#define BK_MAX_BLOCKS 512
-#define BK_UNIT 2048 /* entries per work unit of phase 1 */
+#define BB_WIN 256           /* entries per window: 64 lanes x 4 */
+#define BB_MAX_STRIPES 2048  /* per-wave cursors of the builder in LDS */
+#define BB_P1_WAVES 16
 
 #define BKCHK(expr)                                                                                  \
     do {                                                                                             \
@@ -47,69 +57,84 @@ namespace {
         }                                                                                            \
     } while (0)
 
-__device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
+/* elements of x a workgroup of phase 1 keeps in LDS; the last one is the zero column the pads point to */
+template <typename T> struct BlkGeom {
+    static constexpr int W = sizeof(T) == 8 ? 20480 : 32768; /* 160 KB of doubles; 15-bit columns of floats */
+};
 
 /* ---------------------------------------------------------------- phase 1 */
+/* workgroup q: stripe wg[3q], windows [wg[3q+1], wg[3q+2]) of the phase-1 stream.  Inside a window the values lie
+ * lane-interleaved in 16-byte units (entry i of lane l at (i / E) * 64 E + l E + i % E, as in STRIPED) so that every load
+ * is a dense 1-KiB wave access; the columns are linear (8 bytes per lane). */
 template <typename T, int U>
-__global__ void __launch_bounds__(256) k_blk_sums(const T *__restrict__ bval, const unsigned int *__restrict__ bcol,
-                                                  const int *__restrict__ unit_cell, const int *__restrict__ blk_unit0,
-                                                  const int *__restrict__ cell_ent, const int *__restrict__ cell_seg,
-                                                  int nblk, const T *__restrict__ x, T *__restrict__ seg_sum)
+__global__ void __launch_bounds__(BB_P1_WAVES * 64) k_blk_products(const int *__restrict__ wg, const T *__restrict__ val,
+                                                                   const unsigned short *__restrict__ col,
+                                                                   const unsigned int *__restrict__ dest4,
+                                                                   const T *__restrict__ x, int cols, int wcols,
+                                                                   T *__restrict__ prod)
 {
-    const int lane = threadIdx.x & 63;
-    const int xcd = blockIdx.x & 7;
-    const int wave_in_xcd = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
-    const int waves_per_xcd = (gridDim.x >> 3) * 4;
-    for (int b = xcd; b < nblk; b += 8) {
-        const int u1 = blk_unit0[b + 1];
-        for (int u = blk_unit0[b] + wave_in_xcd; u < u1; u += waves_per_xcd) {
-            const int c0 = unit_cell[2 * u], c1 = unit_cell[2 * u + 1]; /* first and end cell of the unit */
-            const int e0 = cell_ent[c0], e1 = cell_ent[c1];
-            int s = cell_seg[c0];
-            T carry = (T)0; /* open sum of the segment that spans the boundary of two groups of 64 */
-            for (int eb = e0; eb < e1; eb += 64 * U) {
-                T a[U];
-                unsigned int ci[U];
+    using VT = typename Vec16<T>::val_t;
+    constexpr int E = Vec16<T>::E, NV = 4 / E, W = BlkGeom<T>::W, NT = BB_P1_WAVES * 64;
+    __shared__ __attribute__((aligned(16))) T s_x[W];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int s = __builtin_amdgcn_readfirstlane(wg[3 * blockIdx.x]);
+    const int w0 = __builtin_amdgcn_readfirstlane(wg[3 * blockIdx.x + 1]), w1 = __builtin_amdgcn_readfirstlane(wg[3 * blockIdx.x + 2]);
+    const int n = w1 - w0;
+    const int a = w0 + (int)((long long)n * w / BB_P1_WAVES), b = w0 + (int)((long long)n * (w + 1) / BB_P1_WAVES);
+
+    VT v[U][NV];
+    u32x2 c[U];
+    unsigned int d[U];
+    auto load = [&](int u, int kk) __attribute__((always_inline)) {
+        kk = kk < b ? kk : b - 1; /* beyond the wave's share: its last window again (loaded, not used) */
+        kk = kk < w0 ? w0 : kk;   /* a wave without a share (fewer windows than waves) */
+        const size_t base = (size_t)kk * BB_WIN;
 #pragma unroll
-                for (int k = 0; k < U; ++k) { /* every load of U groups, then every gather, before the first scan */
-                    const int me = eb + k * 64 + lane;
-                    const bool ok = me < e1;
-                    a[k] = ok ? bval[me] : (T)0;
-                    ci[k] = ok ? bcol[me] : 0u;
-                }
-                T v[U];
+        for (int j = 0; j < NV; ++j)
+            v[u][j] = ld<VT, true>(reinterpret_cast<const VT *>(val + base + (size_t)(j * 64 * E)) + lane);
+        c[u] = ld<u32x2, true>(reinterpret_cast<const u32x2 *>(col + base) + lane);
+        d[u] = __builtin_nontemporal_load(dest4 + base / 4 + lane);
+    };
+    /* the first U windows are on their way while x is staged */
 #pragma unroll
-                for (int k = 0; k < U; ++k)
-                    v[k] = a[k] * x[ci[k] & 0x7fffffffu];
+    for (int u = 0; u < U; ++u)
+        load(u, a + u);
+    {
+        const int c0 = s * wcols;
+        const int nx = (cols - c0) < wcols ? (cols - c0) : wcols;
+        const T *xs = x + c0;
+        for (int i = tid * E; i < W; i += NT * E) {
+            VT xv;
+            if (i + E <= nx) {
+                xv = *reinterpret_cast<const VT *>(xs + i);
+            } else {
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    if (eb + k * 64 >= e1) /* wave-uniform */
-                        break;
-                    const bool ok = eb + k * 64 + lane < e1;
-                    const int fend = ok ? (int)(ci[k] >> 31) : 0;
-                    /* a lane starts a segment when the lane below it ended one; lane 0 when no sum is open */
-                    int fstart = dpp_mov<0x138, 0xf>(fend); /* wave_shr:1 */
-                    if (lane == 0)
-                        fstart = 0; /* the open sum (carry) is added below where no start precedes the lane */
-                    T sv = ok ? v[k] : (T)0;
-                    int sf = fstart;
-                    segscan_step<T, 0x111, 0xf>(sv, sf); /* row_shr:1 */
-                    segscan_step<T, 0x112, 0xf>(sv, sf); /* row_shr:2 */
-                    segscan_step<T, 0x114, 0xf>(sv, sf); /* row_shr:4 */
-                    segscan_step<T, 0x118, 0xf>(sv, sf); /* row_shr:8 */
-                    segscan_step<T, 0x142, 0xa>(sv, sf); /* row_bcast:15 */
-                    segscan_step<T, 0x143, 0xc>(sv, sf); /* row_bcast:31 */
-                    if (!sf)
-                        sv = sv + carry; /* no segment start at or before this lane: the previous group's open sum */
-                    const unsigned long long ends = __ballot(fend != 0);
-                    if (fend) {
-                        const unsigned int before = __builtin_amdgcn_mbcnt_hi((unsigned int)(ends >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((unsigned int)ends, 0));
-                        seg_sum[s + (int)before] = sv;
-                    }
-                    s += __builtin_popcountll(ends);
-                    const T last = __shfl(sv, 63, 64);
-                    carry = (ends >> 63) ? (T)0 : last; /* lanes beyond e1 hold the last valid lane's sum (they add 0) */
+                for (int e = 0; e < E; ++e)
+                    xv[e] = i + e < nx ? xs[i + e] : (T)0; /* beyond the stripe: zeros, the zero column W - 1 among them */
+            }
+            *reinterpret_cast<VT *>(&s_x[i]) = xv;
+        }
+    }
+    __syncthreads();
+    for (int k = a; k < b; k += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            T p[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned int ci = (i & 1) ? (c[u][i >> 1] >> 16) : (c[u][i >> 1] & 0xffffu);
+                p[i] = v[u][i / E][i % E] * s_x[ci];
+            }
+            T *out = prod + (size_t)d[u] * 4;
+            load(u, k + u + U);
+            if (k + u < b) { /* wave-uniform */
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    VT o;
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        o[e] = p[j * E + e];
+                    reinterpret_cast<VT *>(out)[j] = o;
                 }
             }
         }
@@ -117,233 +142,187 @@ __global__ void __launch_bounds__(256) k_blk_sums(const T *__restrict__ bval, co
 }
 
 /* ---------------------------------------------------------------- phase 2 */
-template <typename T>
-__global__ void __launch_bounds__(256) k_blk_rows(const unsigned long long *__restrict__ cell_mask,
-                                                  const int *__restrict__ cell_seg, const T *__restrict__ seg_sum,
-                                                  T *__restrict__ y, int rows, int nrg, int nblk)
+/* one wave per bin: windows [bw[b], bw[b+1]) of the phase-2 stream, rows [b RB, b RB + RB).  The stream is linear: lane l
+ * takes the products j * 64 E + l E .. + E - 1 of a window with its j-th 16-byte load */
+template <typename T, int U, int RB>
+__global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ bw, const T *__restrict__ prod,
+                                                  const unsigned short *__restrict__ lrow, int rows, int nbins,
+                                                  T *__restrict__ y)
 {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = lanes_below(lane);
-    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < nrg; g += gridDim.x * 4) {
-        T acc = (T)0;
-        int b = 0;
-        for (; b + 4 <= nblk; b += 4) { /* four blocks' loads in flight, added in block order */
-            unsigned long long m[4];
-            int base[4];
+    using VT = typename Vec16<T>::val_t;
+    constexpr int E = Vec16<T>::E, NV = 4 / E;
+    typedef unsigned short rows_t __attribute__((ext_vector_type(E)));
+    __shared__ __attribute__((aligned(16))) T s_y[4][RB];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= nbins)
+        return;
+    for (int i = lane; i < RB; i += 64)
+        s_y[w][i] = (T)0;
+    __builtin_amdgcn_wave_barrier();
+    const int a = __builtin_amdgcn_readfirstlane(bw[b]), e = __builtin_amdgcn_readfirstlane(bw[b + 1]);
+    if (a < e) {
+        VT v[U][NV];
+        rows_t r[U][NV];
+        auto load = [&](int u, int kk) __attribute__((always_inline)) {
+            kk = kk < e ? kk : e - 1;
+            const size_t base = (size_t)kk * BB_WIN;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const size_t i = (size_t)(b + k) * nrg + g;
-                m[k] = cell_mask[i];
-                base[k] = cell_seg[i];
+            for (int j = 0; j < NV; ++j) {
+                v[u][j] = reinterpret_cast<const VT *>(prod + base + (size_t)(j * 64 * E))[lane]; /* written a moment ago: may still be cached */
+                r[u][j] = __builtin_nontemporal_load(reinterpret_cast<const rows_t *>(lrow + base + (size_t)(j * 64 * E)) + lane);
             }
-            T v[4];
+        };
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                v[k] = (m[k] >> lane) & 1ull ? seg_sum[base[k] + __builtin_popcountll(m[k] & below)] : (T)0;
+        for (int u = 0; u < U; ++u)
+            load(u, a + u);
+        for (int k = a; k < e; k += U) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((m[k] >> lane) & 1ull)
-                    acc = acc + v[k];
+            for (int u = 0; u < U; ++u) {
+                VT q[NV];
+                rows_t rr[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    q[j] = v[u][j], rr[j] = r[u][j];
+                load(u, k + u + U);
+                if (k + u < e) { /* wave-uniform */
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+#pragma unroll
+                        for (int i = 0; i < E; ++i)
+                            unsafeAtomicAdd(&s_y[w][rr[j][i] & (RB - 1)], q[j][i]);
+                }
+            }
         }
-        for (; b < nblk; ++b) {
-            const size_t i = (size_t)b * nrg + g;
-            const unsigned long long m = cell_mask[i];
-            if ((m >> lane) & 1ull)
-                acc = acc + seg_sum[cell_seg[i] + __builtin_popcountll(m & below)];
-        }
-        const int r = g * 64 + lane;
-        if (r < rows)
-            y[r] = acc;
     }
+    __builtin_amdgcn_wave_barrier();
+    const int r0 = b * RB;
+    for (int i = lane; i < RB && r0 + i < rows; i += 64)
+        y[r0 + i] = s_y[w][i];
 }
 
 /* ---------------------------------------------------------------- the builder */
-/* wave per row group: entries, segments and row mask of every (block, row group) cell; lane l walks row 64 g + l */
-__global__ void __launch_bounds__(256) k_bk_cells(const int *__restrict__ rowptr, const int *__restrict__ col, int rows,
-                                                  int nrg, int nblk, int CB, int *__restrict__ cell_ent,
-                                                  int *__restrict__ cell_seg, unsigned long long *__restrict__ cell_mask,
-                                                  int *__restrict__ flags)
+/* the row of CSR position j: the last r in [lo, hi] with rowptr[r] <= j */
+__device__ __forceinline__ int row_of(const int *__restrict__ rowptr, int lo, int hi, int j)
 {
-    __shared__ int s_e[4][BK_MAX_BLOCKS];
-    __shared__ int s_s[4][BK_MAX_BLOCKS];
-    __shared__ unsigned long long s_m[4][BK_MAX_BLOCKS];
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rowptr[mid] <= j)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+/* entries per (stripe, bin) cell: cnt[s * B + b] */
+__global__ void __launch_bounds__(256) k_bb_count(const int *__restrict__ rowptr, const int *__restrict__ col, int rows,
+                                                  int nnz, int wcols, int rb_shift, int B, int *__restrict__ cnt)
+{
+    for (long long jj = (long long)blockIdx.x * 256 + threadIdx.x; jj < nnz; jj += (long long)gridDim.x * 256) {
+        const int j = (int)jj;
+        const int r = row_of(rowptr, 0, rows - 1, j);
+        atomicAdd(&cnt[(size_t)((col[j] - 1) / wcols) * B + (r >> rb_shift)], 1);
+    }
+}
+
+/* wave per bin: every entry of the bin's rows, in CSR order, to place (rank inside its cell) of both streams.  The rank is
+ * counted, not drawn from an atomic: per 64 entries one turn per distinct stripe among them, so the layout is the same
+ * in every build. */
+template <typename T>
+__global__ void __launch_bounds__(256) k_bb_scatter(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                    const T *__restrict__ val, int rows, int rb_shift, int B, int S,
+                                                    int wcols, const unsigned int *__restrict__ c1q,
+                                                    const unsigned int *__restrict__ c2q, T *__restrict__ val1,
+                                                    unsigned short *__restrict__ col1, unsigned short *__restrict__ lrow)
+{
+    constexpr int E = Vec16<T>::E;
+    __shared__ volatile unsigned int s_cur[4][BB_MAX_STRIPES];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int bad_order = 0;
-    for (int g = blockIdx.x * 4 + w; g < nrg; g += gridDim.x * 4) {
-        for (int b = lane; b < nblk; b += 64)
-            s_e[w][b] = 0, s_s[w][b] = 0, s_m[w][b] = 0ull;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
+        for (int s = lane; s < S; s += 64)
+            s_cur[w][s] = 0u;
         __builtin_amdgcn_wave_barrier();
-        const int r = g * 64 + lane;
-        if (r < rows && nblk <= 64) {
-            /* up to 64 blocks: the blocks a row touches fit one 64-bit mask, so its columns may come in any order (the
-             * SparseBench matrix as the Fortran reader sees it, SURVEY quirk N1, has rows that are not sorted) */
-            unsigned long long touched = 0ull;
-            int prev = -1;
-            for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) {
-                const int c = col[p] - 1;
-                bad_order |= c < prev;
-                prev = c;
-                atomicAdd(&s_e[w][c / CB], 1);
-                touched |= 1ull << (c / CB);
-            }
-            while (touched) {
-                const int b = __builtin_ctzll(touched);
-                touched &= touched - 1ull;
-                atomicAdd(&s_s[w][b], 1);
-                atomicOr(&s_m[w][b], 1ull << lane);
-            }
-        } else if (r < rows) {
-            int p = rowptr[r];
-            const int e = rowptr[r + 1];
-            int prev = -1;
-            while (p < e) {
-                const int c = col[p] - 1;
-                const int b = c / CB;
-                bad_order |= c < prev;
-                int n = 1;
-                prev = c;
-                while (p + n < e) {
-                    const int c2 = col[p + n] - 1;
-                    if (c2 / CB != b)
-                        break;
-                    bad_order |= c2 < prev;
-                    prev = c2;
-                    ++n;
+        const int r0 = b << rb_shift;
+        const int r1 = (r0 + (1 << rb_shift)) < rows ? r0 + (1 << rb_shift) : rows;
+        const int e0 = rowptr[r0], e1 = rowptr[r1];
+        for (int base = e0; base < e1; base += 64) {
+            const int j = base + lane;
+            const bool ok = j < e1;
+            const int c = ok ? col[j] - 1 : 0;
+            const int s = c / wcols;
+            const int r = ok ? row_of(rowptr, r0, r1 - 1, j) : r0;
+            bool pending = ok;
+            unsigned int rank = 0u;
+            unsigned long long m;
+            while ((m = __ballot(pending)) != 0ull) {
+                const int leader = __builtin_ctzll(m);
+                const int ks = __shfl(s, leader, 64);
+                const bool same = pending && s == ks;
+                const unsigned long long mm = __ballot(same);
+                const unsigned int first = s_cur[w][ks];
+                if (same) {
+                    rank = first + (unsigned int)__builtin_popcountll(mm & below);
+                    pending = false;
                 }
-                atomicAdd(&s_e[w][b], n);
-                atomicAdd(&s_s[w][b], 1);
-                atomicOr(&s_m[w][b], 1ull << lane);
-                p += n;
+                if (lane == leader)
+                    s_cur[w][ks] = first + (unsigned int)__builtin_popcountll(mm);
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ok) {
+                const size_t id = (size_t)s * B + b;
+                const size_t p1 = (size_t)c1q[id] * 4 + rank, p2 = (size_t)c2q[id] * 4 + rank;
+                const size_t wb = p1 / BB_WIN * BB_WIN;
+                const unsigned int o = (unsigned int)(p1 % BB_WIN), l = o / 4, i = o % 4;
+                val1[wb + (i / E) * (64 * E) + l * E + (i % E)] = val[j];
+                col1[p1] = (unsigned short)(c - s * wcols);
+                lrow[p2] = (unsigned short)(r - r0);
             }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int b = lane; b < nblk; b += 64) {
-            const size_t i = (size_t)b * nrg + g;
-            cell_ent[i] = s_e[w][b];
-            cell_seg[i] = s_s[w][b];
-            cell_mask[i] = s_m[w][b];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (bad_order)
-        flags[0] = 1;
-}
-
-/* exclusive scan of two int arrays in pieces of 2048: in place, the piece totals to tot[2 * piece + {0, 1}] */
-__global__ void __launch_bounds__(256) k_bk_scan_local(int *__restrict__ a0, int *__restrict__ a1, size_t n,
-                                                       long long *__restrict__ tot)
-{
-    __shared__ int s_w[2][4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t base = (size_t)blockIdx.x * 2048 + (size_t)tid * 8;
-    int v0[8], v1[8], sum0 = 0, sum1 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        v0[i] = base + i < n ? a0[base + i] : 0;
-        v1[i] = base + i < n ? a1[base + i] : 0;
-        sum0 += v0[i], sum1 += v1[i];
-    }
-    int inc0 = sum0, inc1 = sum1;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t0 = __shfl_up(inc0, o, 64), t1 = __shfl_up(inc1, o, 64);
-        if (lane >= o)
-            inc0 += t0, inc1 += t1;
-    }
-    if (lane == 63)
-        s_w[0][w] = inc0, s_w[1][w] = inc1;
-    __syncthreads();
-    int b0 = inc0 - sum0, b1 = inc1 - sum1;
-    for (int k = 0; k < w; ++k)
-        b0 += s_w[0][k], b1 += s_w[1][k];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (base + i < n)
-            a0[base + i] = b0, a1[base + i] = b1;
-        b0 += v0[i], b1 += v1[i];
-    }
-    if (tid == 0) {
-        tot[2 * (size_t)blockIdx.x] = (long long)s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3];
-        tot[2 * (size_t)blockIdx.x + 1] = (long long)s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3];
     }
 }
 
-/* adds the pieces' offsets (off[2 * piece + {0,1}]); entry n of each array = the grand total */
-__global__ void __launch_bounds__(256) k_bk_scan_add(int *__restrict__ a0, int *__restrict__ a1, size_t n,
-                                                     const long long *__restrict__ off, long long total0, long long total1)
+/* thread per cell: the destination of each of its groups of four products */
+__global__ void __launch_bounds__(256) k_bb_dest(const unsigned int *__restrict__ c1q, const unsigned int *__restrict__ c2q,
+                                                 size_t ncells, unsigned int *__restrict__ dest4)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        a0[i] += (int)off[2 * (i / 2048)];
-        a1[i] += (int)off[2 * (i / 2048) + 1];
-    } else if (i == n) {
-        a0[n] = (int)total0;
-        a1[n] = (int)total1;
-    }
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= ncells)
+        return;
+    const unsigned int a = c1q[id], n = c1q[id + 1] - a, d = c2q[id];
+    for (unsigned int q = 0; q < n; ++q)
+        dest4[a + q] = d + q;
 }
 
-/* wave per row group: block after block, every lane's run of the block goes behind the runs of the lanes below it */
-template <typename T, bool SORTED>
-__global__ void __launch_bounds__(256) k_bk_scatter(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                    const T *__restrict__ val, int rows, int nrg, int nblk, int CB,
-                                                    const int *__restrict__ cell_ent,
-                                                    const unsigned long long *__restrict__ cell_mask,
-                                                    T *__restrict__ bval, unsigned int *__restrict__ bcol)
+__global__ void __launch_bounds__(256) k_bb_fill16(unsigned short *__restrict__ p, size_t n, int v)
 {
-    const int lane = threadIdx.x & 63;
-    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < nrg; g += gridDim.x * 4) {
-        const int r = g * 64 + lane;
-        int p = r < rows ? rowptr[r] : 0;
-        const int e = r < rows ? rowptr[r + 1] : 0;
-        for (int b = 0; b < nblk; ++b) {
-            const size_t i = (size_t)b * nrg + g;
-            if (cell_mask[i] == 0ull) /* wave-uniform: no row of the group has an entry in this block */
-                continue;
-            int n = 0;
-            if constexpr (SORTED) {
-                while (p + n < e && (col[p + n] - 1) / CB == b)
-                    ++n;
-            } else { /* the row's entries of this block lie anywhere in the row: count them, keep their order */
-                for (int q = p; q < e; ++q)
-                    n += (col[q] - 1) / CB == b;
-            }
-            int inc = n;
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(inc, o, 64);
-                if (lane >= o)
-                    inc += t;
-            }
-            const int dst = cell_ent[i] + inc - n;
-            if constexpr (SORTED) {
-                for (int k = 0; k < n; ++k) {
-                    bval[dst + k] = val[p + k];
-                    bcol[dst + k] = (unsigned int)(col[p + k] - 1) | (k == n - 1 ? 0x80000000u : 0u);
-                }
-                p += n;
-            } else {
-                int k = 0;
-                for (int q = p; q < e && k < n; ++q)
-                    if ((col[q] - 1) / CB == b) {
-                        bval[dst + k] = val[q];
-                        bcol[dst + k] = (unsigned int)(col[q] - 1) | (k == n - 1 ? 0x80000000u : 0u);
-                        ++k;
-                    }
-            }
-        }
-    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        p[i] = (unsigned short)v;
 }
+
+int g_blk_bin_rows = 2048; /* rows per bin of phase 2 (tuning key 18: 1024, 2048, 4096), read when a layout is built */
 
 } // namespace
 
 extern "C" void spmv_blocked_free(spmv_dev_blocked *d)
 {
-    (void)hipFree(d->bval), (void)hipFree(d->bcol), (void)hipFree(d->cell_ent), (void)hipFree(d->cell_seg);
-    (void)hipFree(d->cell_mask), (void)hipFree(d->unit_cell), (void)hipFree(d->blk_unit0), (void)hipFree(d->seg_sum);
+    (void)hipFree(d->val1), (void)hipFree(d->col1), (void)hipFree(d->dest4), (void)hipFree(d->wg);
+    (void)hipFree(d->prod), (void)hipFree(d->lrow), (void)hipFree(d->bw);
     memset(d, 0, sizeof *d);
+}
+
+extern "C" void spmvk_blocked_set_wgs(int bin_rows)
+{
+    if (bin_rows == 1024 || bin_rows == 2048 || bin_rows == 4096)
+        g_blk_bin_rows = bin_rows;
 }
 
 /*
  * Builds the BLOCKED layout of a device-resident CSR block (d_rowptr 0-based and local, d_col 1-based).  0; -2: not
- * representable (more than 512 column blocks; rows not sorted by column when there are more than 64); -3: out of memory; -1: a HIP error.
+ * representable (more than 2048 column stripes, more than 2^24 cells, a stream beyond 2^31 entries); -3: out of memory;
+ * -1: a HIP error.
  */
 extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, const void *d_val, int rows, int cols,
                                          int elem_size, int64_t nnz, void *stream, spmv_dev_blocked *out)
@@ -351,132 +330,172 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     memset(out, 0, sizeof *out);
-    const int CB = SPMV_BLOCKED_XBYTES / elem_size;
-    const int nblk = cols > 0 ? (cols + CB - 1) / CB : 1;
-    const int nrg = (rows + 63) / 64;
-    if (rows <= 0 || nnz <= 0 || nblk > BK_MAX_BLOCKS || nnz > 0x7ffffff0ll)
+    if (rows <= 0 || cols <= 0 || nnz <= 0 || nnz > 0x7ffffff0ll)
         return -2;
-    const size_t nc = (size_t)nblk * nrg;
-    const size_t npieces = (nc + 2047) / 2048;
-    int *d_flags = nullptr;
-    long long *d_tot = nullptr, *h_tot = nullptr;
-    int *h_ent = nullptr, *unit_cell = nullptr, *blk_unit0 = nullptr;
-    int flag = 0;
+    /* ---- geometry: as few stripes as the LDS allows, in multiples of 256 (one per CU and round); narrow matrices get
+     * stripes of at least 64 columns */
+    const int E = 16 / elem_size;
+    const int W = elem_size == 8 ? BlkGeom<double>::W : BlkGeom<float>::W;
+    int S, wcols;
+    if (cols <= 256 * 64) {
+        wcols = 64;
+        S = (cols + wcols - 1) / wcols;
+    } else {
+        int k = 1;
+        while ((int64_t)256 * k * (W - E) < cols)
+            ++k;
+        S = 256 * k;
+        wcols = (cols + S - 1) / S;
+        wcols = (wcols + E - 1) / E * E;
+        S = (cols + wcols - 1) / wcols;
+    }
+    const int RB = g_blk_bin_rows;
+    const int rb_shift = RB == 1024 ? 10 : RB == 2048 ? 11 : 12;
+    const int B = (rows + RB - 1) / RB;
+    const size_t ncells = (size_t)S * (size_t)B;
+    if (S > BB_MAX_STRIPES || ncells > ((size_t)1 << 24))
+        return -2;
+
+    int *d_cnt = nullptr, *h_cnt = nullptr, *h_wg = nullptr, *h_bw = nullptr;
+    unsigned int *d_c1q = nullptr, *d_c2q = nullptr, *h_c1q = nullptr, *h_c2q = nullptr;
+    int64_t *stripe_w0 = nullptr;
+    int64_t n1 = 0, n2 = 0;
+    int n_wg = 0;
     spmv_dev_blocked d;
     memset(&d, 0, sizeof d);
-    const int grid_g = nrg < 4 * 8192 ? (nrg + 3) / 4 : 8192;
 
-    BKCHK(hipMalloc((void **)&d.cell_ent, (nc + 1) * sizeof(int)));
-    BKCHK(hipMalloc((void **)&d.cell_seg, (nc + 1) * sizeof(int)));
-    BKCHK(hipMalloc((void **)&d.cell_mask, nc * sizeof(unsigned long long)));
-    BKCHK(hipMalloc((void **)&d_flags, sizeof(int)));
-    BKCHK(hipMalloc((void **)&d_tot, 2 * npieces * sizeof(long long)));
-    h_tot = (long long *)malloc(2 * npieces * sizeof(long long));
-    h_ent = (int *)malloc((nc + 1) * sizeof(int));
-    blk_unit0 = (int *)malloc(((size_t)nblk + 1) * sizeof(int));
-    if (!h_tot || !h_ent || !blk_unit0) {
+    h_cnt = (int *)malloc(ncells * sizeof(int));
+    h_c1q = (unsigned int *)malloc((ncells + 1) * sizeof(unsigned int));
+    h_c2q = (unsigned int *)malloc(ncells * sizeof(unsigned int));
+    stripe_w0 = (int64_t *)malloc(((size_t)S + 1) * sizeof(int64_t));
+    h_bw = (int *)malloc(((size_t)B + 1) * sizeof(int));
+    if (!h_cnt || !h_c1q || !h_c2q || !stripe_w0 || !h_bw) {
         rc = -3;
         goto out;
     }
-    BKCHK(hipMemsetAsync(d_flags, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_bk_cells, dim3(grid_g), dim3(256), 0, st, d_rowptr, d_col, rows, nrg, nblk, CB, d.cell_ent, d.cell_seg,
-                       d.cell_mask, d_flags);
-    hipLaunchKernelGGL(k_bk_scan_local, dim3((unsigned int)npieces), dim3(256), 0, st, d.cell_ent, d.cell_seg, nc, d_tot);
+    /* ---- pass 1: entries per cell */
+    BKCHK(hipMalloc((void **)&d_cnt, ncells * sizeof(int)));
+    BKCHK(hipMemsetAsync(d_cnt, 0, ncells * sizeof(int), st));
+    hipLaunchKernelGGL(k_bb_count, dim3(nnz < 256 * 4096 ? (unsigned int)((nnz + 255) / 256) : 4096u), dim3(256), 0, st, d_rowptr,
+                       d_col, rows, (int)nnz, wcols, rb_shift, B, d_cnt);
     BKCHK(hipGetLastError());
-    BKCHK(hipMemcpyAsync(&flag, d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
-    BKCHK(hipMemcpyAsync(h_tot, d_tot, 2 * npieces * sizeof(long long), hipMemcpyDeviceToHost, st));
+    BKCHK(hipMemcpyAsync(h_cnt, d_cnt, ncells * sizeof(int), hipMemcpyDeviceToHost, st));
     BKCHK(hipStreamSynchronize(st));
-    if (flag && nblk > 64) { /* a row's columns decrease: its (row, block) segments are not runs, and with more than 64
-                                blocks the general path (one block mask per row) does not apply */
-        rc = -2;
-        goto out;
-    }
+    /* ---- the two orders.  Phase 1: stripe-major, cells padded to fours, a stripe's last cell to the window; phase 2:
+     * bin-major with the same padded cells, a bin's end padded to the window (slots nobody writes: they stay zero) */
     {
-        long long run0 = 0, run1 = 0;
-        for (size_t k = 0; k < npieces; ++k) {
-            const long long t0 = h_tot[2 * k], t1 = h_tot[2 * k + 1];
-            h_tot[2 * k] = run0, h_tot[2 * k + 1] = run1;
-            run0 += t0, run1 += t1;
+        int64_t p = 0, total = 0;
+        for (int s = 0; s < S; ++s) {
+            stripe_w0[s] = p / BB_WIN;
+            long long last = -1;
+            for (int b = 0; b < B; ++b) {
+                const size_t id = (size_t)s * B + b;
+                total += h_cnt[id];
+                h_cnt[id] = (h_cnt[id] + 3) & ~3; /* from here on: the padded size */
+                h_c1q[id] = (unsigned int)(p / 4);
+                p += h_cnt[id];
+                if (h_cnt[id])
+                    last = b;
+            }
+            const int64_t q = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
+            if (q != p && last >= 0) {
+                h_cnt[(size_t)s * B + last] += (int)(q - p);
+                for (long long b = last + 1; b < B; ++b)
+                    h_c1q[(size_t)s * B + b] = (unsigned int)(q / 4);
+                p = q;
+            }
+            if (p > ((int64_t)1 << 31) - 4 * BB_WIN) {
+                rc = -2;
+                goto out;
+            }
         }
-        if (run0 != nnz || run1 > 0x7ffffff0ll) {
-            spmv_set_error("BLOCKED builder: %lld entries counted, %lld expected", run0, (long long)nnz);
+        stripe_w0[S] = p / BB_WIN;
+        h_c1q[ncells] = (unsigned int)(p / 4);
+        n1 = p;
+        if (total != nnz) {
+            spmv_set_error("BLOCKED builder: %lld entries counted, %lld expected", (long long)total, (long long)nnz);
             rc = -1;
             goto out;
         }
-        d.nseg = (int64_t)run1;
-        BKCHK(hipMemcpyAsync(d_tot, h_tot, 2 * npieces * sizeof(long long), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_bk_scan_add, dim3((unsigned int)((nc + 1 + 255) / 256)), dim3(256), 0, st, d.cell_ent, d.cell_seg, nc,
-                           d_tot, run0, run1);
-        BKCHK(hipGetLastError());
-    }
-    /* the entries to their places, while the host cuts the work units from the cells' entry counts */
-    {
-        const size_t n_alloc = (size_t)nnz + 64 * 8;
-        BKCHK(hipMalloc(&d.bval, n_alloc * (size_t)elem_size));
-        BKCHK(hipMalloc((void **)&d.bcol, n_alloc * sizeof(unsigned int)));
-        BKCHK(hipMalloc(&d.seg_sum, ((size_t)d.nseg + 64) * (size_t)elem_size));
-        BKCHK(hipMemsetAsync((char *)d.bval + (size_t)nnz * elem_size, 0, 64 * 8 * (size_t)elem_size, st));
-        BKCHK(hipMemsetAsync(d.bcol + nnz, 0, 64 * 8 * sizeof(unsigned int), st));
-#define BK_SCATTER(T, SORTED)                                                                                                  \
-    hipLaunchKernelGGL((k_bk_scatter<T, SORTED>), dim3(grid_g), dim3(256), 0, st, d_rowptr, d_col, (const T *)d_val, rows, nrg, \
-                       nblk, CB, d.cell_ent, d.cell_mask, (T *)d.bval, d.bcol)
-        if (elem_size == 8) {
-            if (flag)
-                BK_SCATTER(double, false);
-            else
-                BK_SCATTER(double, true);
-        } else {
-            if (flag)
-                BK_SCATTER(float, false);
-            else
-                BK_SCATTER(float, true);
+        p = 0;
+        for (int b = 0; b < B; ++b) {
+            h_bw[b] = (int)(p / BB_WIN);
+            for (int s = 0; s < S; ++s) {
+                const size_t id = (size_t)s * B + b;
+                h_c2q[id] = (unsigned int)(p / 4);
+                p += h_cnt[id];
+            }
+            p = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
+            if (p > ((int64_t)1 << 31) - 4 * BB_WIN) {
+                rc = -2;
+                goto out;
+            }
         }
-#undef BK_SCATTER
-        BKCHK(hipGetLastError());
-        BKCHK(hipMemcpyAsync(h_ent, d.cell_ent, (nc + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
-        BKCHK(hipStreamSynchronize(st));
+        h_bw[B] = (int)(p / BB_WIN);
+        n2 = p;
     }
+    /* ---- phase 1's workgroups: one per stripe; a stripe with more than 5/4 of the mean share is cut */
     {
-        /* units: runs of whole cells of ONE block holding about BK_UNIT entries (a cell is never split: a segment
-         * belongs to one unit, so no sum crosses units; a cell with a long row makes a long unit); stored as
-         * (first cell, end cell) pairs */
-        const size_t cap = (size_t)(nnz / BK_UNIT) + (size_t)nblk + 2;
-        size_t nu = 0;
-        unit_cell = (int *)malloc(cap * 2 * sizeof(int));
-        if (!unit_cell) {
+        const int64_t slots = S > 256 ? S : 256;
+        int64_t target = (stripe_w0[S] + slots - 1) / slots;
+        target = target * 5 / 4 > 0 ? target * 5 / 4 : 1;
+        size_t cap = 0;
+        for (int s = 0; s < S; ++s)
+            cap += (size_t)((stripe_w0[s + 1] - stripe_w0[s] + target - 1) / target);
+        h_wg = (int *)malloc((cap + 1) * 3 * sizeof(int));
+        if (!h_wg) {
             rc = -3;
             goto out;
         }
-        for (int b = 0; b < nblk; ++b) {
-            blk_unit0[b] = (int)nu;
-            size_t c = (size_t)b * nrg;
-            const size_t cend = (size_t)(b + 1) * nrg;
-            while (c < cend && h_ent[c] < h_ent[cend] && nu < cap) { /* entries left in the block */
-                const long long target = (long long)h_ent[c] + BK_UNIT;
-                unit_cell[2 * nu] = (int)c;
-                ++c;
-                while (c < cend && h_ent[c] < target)
-                    ++c;
-                unit_cell[2 * nu + 1] = (int)c;
-                ++nu;
+        for (int s = 0; s < S; ++s) {
+            const int64_t a = stripe_w0[s], e = stripe_w0[s + 1];
+            const int parts = (int)((e - a + target - 1) / target);
+            for (int q = 0; q < parts; ++q) {
+                h_wg[3 * n_wg] = s;
+                h_wg[3 * n_wg + 1] = (int)(a + (e - a) * q / parts);
+                h_wg[3 * n_wg + 2] = (int)(a + (e - a) * (q + 1) / parts);
+                ++n_wg;
             }
         }
-        blk_unit0[nblk] = (int)nu;
-        d.n_units = (int)nu;
-        BKCHK(hipMalloc((void **)&d.unit_cell, (nu + 1) * 2 * sizeof(int)));
-        BKCHK(hipMalloc((void **)&d.blk_unit0, ((size_t)nblk + 1) * sizeof(int)));
-        BKCHK(hipMemcpyAsync(d.unit_cell, unit_cell, nu * 2 * sizeof(int), hipMemcpyHostToDevice, st));
-        BKCHK(hipMemcpyAsync(d.blk_unit0, blk_unit0, ((size_t)nblk + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-        BKCHK(hipStreamSynchronize(st));
     }
-    d.elem = elem_size, d.rows = rows, d.cols = cols, d.nnz = nnz, d.nblk = nblk, d.nrg = nrg, d.CB = CB;
-    d.bytes = (nc + 1) * 8 + nc * 8 + ((size_t)nnz + 512) * ((size_t)elem_size + 4) + ((size_t)d.nseg + 64) * (size_t)elem_size +
-              ((size_t)d.n_units + 1) * 8 + ((size_t)nblk + 1) * 4;
+    /* ---- pass 2: the entries to their places */
+    BKCHK(hipMalloc((void **)&d_c1q, (ncells + 1) * sizeof(unsigned int)));
+    BKCHK(hipMalloc((void **)&d_c2q, ncells * sizeof(unsigned int)));
+    BKCHK(hipMalloc(&d.val1, (size_t)n1 * (size_t)elem_size));
+    BKCHK(hipMalloc((void **)&d.col1, (size_t)n1 * sizeof(unsigned short)));
+    BKCHK(hipMalloc((void **)&d.dest4, (size_t)n1 / 4 * sizeof(unsigned int)));
+    BKCHK(hipMalloc(&d.prod, (size_t)n2 * (size_t)elem_size));
+    BKCHK(hipMalloc((void **)&d.lrow, (size_t)n2 * sizeof(unsigned short)));
+    BKCHK(hipMalloc((void **)&d.wg, ((size_t)n_wg + 1) * 3 * sizeof(int)));
+    BKCHK(hipMalloc((void **)&d.bw, ((size_t)B + 1) * sizeof(int)));
+    BKCHK(hipMemcpyAsync(d_c1q, h_c1q, (ncells + 1) * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    BKCHK(hipMemcpyAsync(d_c2q, h_c2q, ncells * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    BKCHK(hipMemcpyAsync(d.wg, h_wg, (size_t)n_wg * 3 * sizeof(int), hipMemcpyHostToDevice, st));
+    BKCHK(hipMemcpyAsync(d.bw, h_bw, ((size_t)B + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    BKCHK(hipMemsetAsync(d.val1, 0, (size_t)n1 * (size_t)elem_size, st));
+    BKCHK(hipMemsetAsync(d.prod, 0, (size_t)n2 * (size_t)elem_size, st));
+    BKCHK(hipMemsetAsync(d.lrow, 0, (size_t)n2 * sizeof(unsigned short), st));
+    hipLaunchKernelGGL(k_bb_fill16, dim3(1024), dim3(256), 0, st, d.col1, (size_t)n1, W - 1); /* pads: times the zero column */
+    {
+        const int grid_b = B < 4 * 4096 ? (B + 3) / 4 : 4096;
+        if (elem_size == 8)
+            hipLaunchKernelGGL(k_bb_scatter<double>, dim3(grid_b), dim3(256), 0, st, d_rowptr, d_col, (const double *)d_val, rows,
+                               rb_shift, B, S, wcols, d_c1q, d_c2q, (double *)d.val1, d.col1, d.lrow);
+        else
+            hipLaunchKernelGGL(k_bb_scatter<float>, dim3(grid_b), dim3(256), 0, st, d_rowptr, d_col, (const float *)d_val, rows,
+                               rb_shift, B, S, wcols, d_c1q, d_c2q, (float *)d.val1, d.col1, d.lrow);
+    }
+    hipLaunchKernelGGL(k_bb_dest, dim3((unsigned int)((ncells + 255) / 256)), dim3(256), 0, st, d_c1q, d_c2q, ncells, d.dest4);
+    BKCHK(hipGetLastError());
+    BKCHK(hipStreamSynchronize(st));
+    d.elem = elem_size, d.rows = rows, d.cols = cols, d.nnz = nnz, d.S = S, d.wcols = wcols, d.W = W, d.RB = RB, d.B = B;
+    d.n_wg = n_wg, d.n1 = n1, d.n2 = n2;
+    d.bytes = (size_t)n1 * ((size_t)elem_size + 3) + (size_t)n2 * ((size_t)elem_size + 2) + ((size_t)n_wg + 1) * 12 + ((size_t)B + 1) * 4;
     *out = d;
     memset(&d, 0, sizeof d);
 out:
-    (void)hipFree(d_flags), (void)hipFree(d_tot);
-    free(h_tot), free(h_ent), free(unit_cell), free(blk_unit0);
+    (void)hipFree(d_cnt), (void)hipFree(d_c1q), (void)hipFree(d_c2q);
+    free(h_cnt), free(h_c1q), free(h_c2q), free(stripe_w0), free(h_bw), free(h_wg);
     if (rc != 0) {
         (void)hipGetLastError();
         spmv_blocked_free(&d);
@@ -484,11 +503,17 @@ out:
     return rc;
 }
 
-static int g_blk_wgs_per_xcd = 256; /* phase 1: workgroups per XCD (8 per CU: 32 waves, each with 4 x 64 entries in flight) */
-extern "C" void spmvk_blocked_set_wgs(int per_xcd)
+template <typename T> static void launch_blocked(const spmv_dev_blocked *d, const void *x, void *y, hipStream_t st)
 {
-    if (per_xcd >= 1 && per_xcd <= 4096)
-        g_blk_wgs_per_xcd = per_xcd;
+    hipLaunchKernelGGL((k_blk_products<T, 4>), dim3(d->n_wg), dim3(BB_P1_WAVES * 64), 0, st, d->wg, (const T *)d->val1, d->col1,
+                       d->dest4, (const T *)x, d->cols, d->wcols, (T *)d->prod);
+    const dim3 g2((d->B + 3) / 4);
+    if (d->RB == 1024)
+        hipLaunchKernelGGL((k_blk_bins<T, 4, 1024>), g2, dim3(256), 0, st, d->bw, (const T *)d->prod, d->lrow, d->rows, d->B, (T *)y);
+    else if (d->RB == 2048)
+        hipLaunchKernelGGL((k_blk_bins<T, 4, 2048>), g2, dim3(256), 0, st, d->bw, (const T *)d->prod, d->lrow, d->rows, d->B, (T *)y);
+    else
+        hipLaunchKernelGGL((k_blk_bins<T, 4, 4096>), g2, dim3(256), 0, st, d->bw, (const T *)d->prod, d->lrow, d->rows, d->B, (T *)y);
 }
 
 extern "C" int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *stream)
@@ -496,19 +521,9 @@ extern "C" int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, 
     hipStream_t st = (hipStream_t)stream;
     if (d->rows <= 0)
         return 0;
-    /* phase 1: 8 XCDs x K workgroups; every XCD takes the column blocks b = its id (mod 8) */
-    const int k1 = 8 * g_blk_wgs_per_xcd;
-    const int g2 = d->nrg < 4 * 4096 ? (d->nrg + 3) / 4 : 4096;
-    if (d->elem == 8) {
-        hipLaunchKernelGGL((k_blk_sums<double, 4>), dim3(k1), dim3(256), 0, st, (const double *)d->bval, d->bcol, d->unit_cell,
-                           d->blk_unit0, d->cell_ent, d->cell_seg, d->nblk, (const double *)x, (double *)d->seg_sum);
-        hipLaunchKernelGGL(k_blk_rows<double>, dim3(g2), dim3(256), 0, st, d->cell_mask, d->cell_seg, (const double *)d->seg_sum,
-                           (double *)y, d->rows, d->nrg, d->nblk);
-    } else {
-        hipLaunchKernelGGL((k_blk_sums<float, 4>), dim3(k1), dim3(256), 0, st, (const float *)d->bval, d->bcol, d->unit_cell,
-                           d->blk_unit0, d->cell_ent, d->cell_seg, d->nblk, (const float *)x, (float *)d->seg_sum);
-        hipLaunchKernelGGL(k_blk_rows<float>, dim3(g2), dim3(256), 0, st, d->cell_mask, d->cell_seg, (const float *)d->seg_sum,
-                           (float *)y, d->rows, d->nrg, d->nblk);
-    }
+    if (d->elem == 8)
+        launch_blocked<double>(d, x, y, st);
+    else
+        launch_blocked<float>(d, x, y, st);
     return (int)hipGetLastError();
 }

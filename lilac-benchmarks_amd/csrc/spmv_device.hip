@@ -702,7 +702,7 @@ static int ensure_blocked(spmv_hip_matrix *m)
     }
     m->blocked_rc = rc;
     if (rc == -2)
-        spmv_set_error("matrix not representable in the BLOCKED layout (more than 512 column blocks, or more than 64 and rows not sorted by column)");
+        spmv_set_error("matrix not representable in the BLOCKED layout (more than 2048 column stripes or 2^24 cells)");
     else if (rc == -3)
         spmv_set_error("out of memory for the BLOCKED layout");
     if (rc)
@@ -951,7 +951,7 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
         if (ensure_blocked(m))
             return -1;
         m->plan = plan;
-        m->param = m->db.CB;
+        m->param = m->db.wcols;
         break;
     case SPMV_HIP_PLAN_TILED:
         if (ensure_tiled(m, nullptr, nullptr, 0, false))
@@ -1028,7 +1028,7 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     out->mean_row_len = m->st.mean_len;
     out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED     ? m->dt.B
                     : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.n_wg
-                    : m->plan == SPMV_HIP_PLAN_BLOCKED ? m->db.n_units
+                    : m->plan == SPMV_HIP_PLAN_BLOCKED ? m->db.n_wg
                                                        : m->sp.nblk;
     out->n_long_rows = m->sp.n_long_rows;
     out->n_launches = n_launches(m);
@@ -1411,7 +1411,7 @@ void spmv_hip_set_tuning(int key, int value)
     else if (key == 19 && value >= -200 && value <= 200)
         g_stripe_xcd_bias = value; /* STRIPED: per mille of weight moved from even-XCD workgroups to odd-XCD ones */
     else if (key == 18)
-        spmvk_blocked_set_wgs(value); /* BLOCKED phase 1: workgroups per XCD */
+        spmvk_blocked_set_wgs(value); /* BLOCKED: rows per bin of layouts built from now on */
     else if (key == 17 && value >= 0 && value <= 2)
         g_striped_builder = value; /* 0: the device builds the STRIPED layout (the host when it must), 1: host, 2: device or fail */
     else if (key == 15 && value >= 0 && value <= 2)

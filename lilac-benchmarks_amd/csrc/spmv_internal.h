@@ -220,19 +220,19 @@ typedef struct spmv_dev_striped {
     int xbytes; /* LDS stripe capacity the layout was built for */
     int64_t n_packed; /* entries of the packed stream, pads included */
 } spmv_dev_striped;
-/* BLOCKED (spmv_blocked.hip): entries block-major (column blocks of SPMV_BLOCKED_XBYTES of x), one sum per (row, block)
- * segment, one row mask per (block, 64-row group) cell */
-#define SPMV_BLOCKED_XBYTES (2 << 20) /* bytes of x per column block: half an XCD's L2 */
+/* BLOCKED (spmv_blocked.hip): two phases over (column stripe, row bin) cells.  Phase 1 streams the entries stripe-major
+ * with the stripe of x in LDS and writes the products bin-major; phase 2 streams the products, one wave per bin, into the
+ * bin's slice of y in LDS */
 typedef struct spmv_dev_blocked {
-    void *bval;                    /* T[nnz + pad], block-major                                              */
-    unsigned int *bcol;            /* 0-based column; bit 31 = last entry of its (row, block) segment        */
-    int *cell_ent, *cell_seg;      /* [nblk * nrg + 1] exclusive scans: entries / segments before the cell   */
-    unsigned long long *cell_mask; /* [nblk * nrg] which of the group's 64 rows have a segment in the block  */
-    int *unit_cell;                /* [n_units * 2] (first cell, end cell) of phase 1's work units            */
-    int *blk_unit0;                /* [nblk + 1] first unit of each block                                    */
-    void *seg_sum;                 /* T[nseg] scratch, rewritten by every product                            */
-    int elem, rows, cols, nblk, nrg, CB, n_units;
-    int64_t nnz, nseg;
+    void *val1;        /* T[n1] phase-1 order (stripe, bin, row), lane-interleaved inside windows of 256 entries    */
+    uint16_t *col1;    /* [n1] stripe-local column; pads point to the zero column W - 1                           */
+    uint32_t *dest4;   /* [n1 / 4] phase-2 position / 4 of every four products                                     */
+    int *wg;           /* [n_wg * 3] phase-1 workgroups: stripe, first window, end window                          */
+    void *prod;        /* T[n2] the products in phase-2 order (bin, stripe, row): scratch, rewritten by every call */
+    uint16_t *lrow;    /* [n2] bin-local row of every product                                                      */
+    int *bw;           /* [B + 1] first window of every bin in the phase-2 stream                                  */
+    int elem, rows, cols, S, wcols, W, RB, B, n_wg;
+    int64_t nnz, n1, n2;
     size_t bytes;
 } spmv_dev_blocked;
 int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, const void *d_val, int rows, int cols, int elem_size,

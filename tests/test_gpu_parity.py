@@ -1290,19 +1290,21 @@ def test_striped_is_bit_identical_to_its_documented_order(pkg, backend, planlib,
 
 
 def test_blocked_plan(pkg, backend, oracle):
-    """The BLOCKED plan (csrc/spmv_blocked.hip): entries block-major over 2-MB column blocks of x, one sum per (row, block)
-    segment, rows added in block order.  Its own shapes: several column blocks (x of 5-40 MB), short rows (SparseBench-
-    like), rows that span many groups of 64 entries inside one block (a carry per group), empty rows, more rows than a
-    multiple of 64, a row count below 64; f64 and f32; results within the CSR bar, the same bits on every repetition and
-    after a value refresh; a matrix with unsorted rows is refused."""
+    """The BLOCKED plan (csrc/spmv_blocked.hip): phase 1 streams the entries stripe-major with the stripe of x in LDS and writes
+    the products bin-major, phase 2 adds them, one wave per bin of rows, in LDS.  Its own shapes: several stripes and bins
+    (x of 5-40 MB), short rows (SparseBench-like), long rows (one address of a bin's slice taking thousands of additions),
+    empty rows, a row count below one bin, rows with unsorted and repeated columns; every bin size; f64 and f32; results
+    within the CSR bar, the same bits on every repetition, in a second build of the layout and after a value refresh; a
+    matrix with more columns than 2048 stripes hold is refused."""
     rng = np.random.default_rng(97)
     for dtype in (np.float64, np.float32):
         cases = {
-            "sparsebench_60": matgen.sparsebench_like(98, 60, dtype),                              # 216 000 rows, one block
-            "wide_short_rows": matgen.random_csr(99, 70001, 3_000_000, 5, dtype, empty_frac=0.1, spread=0.6),   # 12 / 6 blocks
-            "wide_long_rows": matgen.random_csr(100, 900, 2_500_000, 700, dtype, spread=0.5),       # segments of ~70 entries
+            "sparsebench_60": matgen.sparsebench_like(98, 60, dtype),                              # 216 000 rows, 106 bins
+            "wide_short_rows": matgen.random_csr(99, 70001, 3_000_000, 5, dtype, empty_frac=0.1, spread=0.6),
+            "wide_long_rows": matgen.random_csr(100, 900, 2_500_000, 700, dtype, spread=0.5),
             "few_rows": matgen.random_csr(101, 37, 1_000_000, 300, dtype, spread=0.2),
             "one_long_row": matgen.csr_from_lengths(rng, [3] * 100 + [200000] + [2] * 200, 700_000, dtype),
+            "unsorted_rows": matgen.random_csr(102, 30000, 3_000_000, 12, dtype, sort_cols=False, distinct=False),
         }
         for name, (rs, ci, a) in cases.items():
             rows = rs.size - 1
@@ -1325,16 +1327,28 @@ def test_blocked_plan(pkg, backend, oracle):
                                   dtype, name + " after a value refresh", CSR)
             finally:
                 m.close()
-    # rows whose columns are not sorted (the SparseBench matrix as the Fortran reader sees it, quirk N1): fine up to 64
-    # column blocks, refused beyond (f32 blocks hold 524288 columns: 40 M columns = 77 blocks)
-    rs, ci, a = matgen.random_csr(102, 30000, 3_000_000, 12, np.float64, sort_cols=False, distinct=False)
+            # a second build of the same matrix gives the same bits: the layout is counted, not drawn from atomics
+            m = backend.matrix(a, rs, ci, rows)
+            try:
+                m.set_plan(pkg.PLAN_BLOCKED, 0)
+                assert np.array_equal(bits(m.spmv_host(x)), bits(y)), name + ": second build"
+            finally:
+                m.close()
+    # every bin size (tuning key 18, read when a layout is built)
+    rs, ci, a = matgen.random_csr(104, 50001, 2_000_000, 7, np.float64, empty_frac=0.05, spread=0.9)
     x = rng.standard_normal(int(ci.max()))
-    m = backend.matrix(a, rs, ci, 30000)
-    m.set_plan(pkg.PLAN_BLOCKED, 0)
-    assert_close_rows(m.spmv_host(x), oracle.spmv(a, x, rs, ci, 30000), oracle.absum(a, x, rs, ci, 30000), np.diff(rs), np.float64,
-                      "unsorted rows", CSR)
-    m.close()
-    rs, ci, a = matgen.random_csr(103, 3000, 40_000_000, 30, np.float32, sort_cols=False)
+    try:
+        for bin_rows in (1024, 4096, 2048):
+            backend.set_tuning(18, bin_rows)
+            m = backend.matrix(a, rs, ci, 50001)
+            m.set_plan(pkg.PLAN_BLOCKED, 0)
+            assert_close_rows(m.spmv_host(x), oracle.spmv(a, x, rs, ci, 50001), oracle.absum(a, x, rs, ci, 50001), np.diff(rs),
+                              np.float64, "bins of %d rows" % bin_rows, CSR)
+            m.close()
+    finally:
+        backend.set_tuning(18, 2048)
+    # more columns than 2048 stripes of 160 KB hold
+    rs, ci, a = matgen.random_csr(103, 3000, 45_000_000, 30, np.float64, sort_cols=False)
     m = backend.matrix(a, rs, ci, 3000)
     with pytest.raises(RuntimeError, match="not representable"):
         m.set_plan(pkg.PLAN_BLOCKED, 0)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""BLOCKED plan on SparseBench-like matrices: phase-1 grid sweep against STREAM.  GPU box only."""
+"""BLOCKED plan on SparseBench-like matrices of several sizes: bin sizes against STREAM.  GPU box only.
+   python3 tools/blockedbench.py [size ...]"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +9,8 @@ import numpy as np  # noqa: E402
 import pkgload  # noqa: E402
 pkg = pkgload.load_package()
 be = pkg.Backend()
-for size in (170, 100):
+sizes = [int(v) for v in sys.argv[1:]] or [170, 100]
+for size in sizes:
     sb = pkg.callers.sb_generate(size)
     rs, ci, a = sb.arrays()
     dm = be.matrix(a, rs, ci, sb.rows)
@@ -18,14 +20,22 @@ for size in (170, 100):
     be.h2d(dx, x)
     dm.set_plan(pkg.PLAN_STREAM, 0)
     dm.time_device(dx, dy, 5)
-    print("sb%d stream %.1f us" % (size, dm.time_device(dx, dy, 20) / 20 * 1e3), flush=True)
-    dm.set_plan(pkg.PLAN_BLOCKED, 0)
-    for wgs in (64, 128, 256, 512, 1024):
-        be.set_tuning(18, wgs)
-        dm.time_device(dx, dy, 5)
-        print("sb%d blocked wgs/xcd=%d %.1f us" % (size, wgs, dm.time_device(dx, dy, 20) / 20 * 1e3), flush=True)
-    be.set_tuning(18, 256)
+    t_stream = dm.time_device(dx, dy, 20) / 20 * 1e3
+    auto = pkg.abi.PLAN_NAMES[inf["plan"]]
     dm.close()
+    line = "sb%d rows=%d nnz=%d x=%.1f MB auto=%s stream %.1f us;" % (size, sb.rows, inf["nnz"], inf["cols"] * 8 / 1e6, auto, t_stream)
+    for bin_rows in (1024, 2048, 4096):
+        be.set_tuning(18, bin_rows)
+        dm = be.matrix(a, rs, ci, sb.rows)
+        import time
+        t0 = time.perf_counter()
+        dm.set_plan(pkg.PLAN_BLOCKED, 0)
+        t_build = time.perf_counter() - t0
+        dm.time_device(dx, dy, 5)
+        line += " blocked/%d %.1f us (built in %.0f ms)" % (bin_rows, dm.time_device(dx, dy, 20) / 20 * 1e3, t_build * 1e3)
+        dm.close()
+    be.set_tuning(18, 2048)
+    print(line, flush=True)
     be.free(dx), be.free(dy)
     del rs, ci, a
     pkg.callers.free(sb)
