@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ bw, co
                     for (int j = 0; j < NV; ++j)
 #pragma unroll
                         for (int i = 0; i < E; ++i)
-                            unsafeAtomicAdd(&s_y[w][rr[j][i] & (RB - 1)], q[j][i]);
+                            unsafeAtomicAdd(&s_y[w][rr[j][i]], q[j][i]);
                 }
             }
         }
@@ -217,12 +217,12 @@ __device__ __forceinline__ int row_of(const int *__restrict__ rowptr, int lo, in
 
 /* entries per (stripe, bin) cell: cnt[s * B + b] */
 __global__ void __launch_bounds__(256) k_bb_count(const int *__restrict__ rowptr, const int *__restrict__ col, int rows,
-                                                  int nnz, int wcols, int rb_shift, int B, int *__restrict__ cnt)
+                                                  int nnz, int wcols, int rb, int B, int *__restrict__ cnt)
 {
     for (long long jj = (long long)blockIdx.x * 256 + threadIdx.x; jj < nnz; jj += (long long)gridDim.x * 256) {
         const int j = (int)jj;
         const int r = row_of(rowptr, 0, rows - 1, j);
-        atomicAdd(&cnt[(size_t)((col[j] - 1) / wcols) * B + (r >> rb_shift)], 1);
+        atomicAdd(&cnt[(size_t)((col[j] - 1) / wcols) * B + r / rb], 1);
     }
 }
 
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) k_bb_count(const int *__restrict__ rowptr
  * in every build. */
 template <typename T>
 __global__ void __launch_bounds__(256) k_bb_scatter(const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                    const T *__restrict__ val, int rows, int rb_shift, int B, int S,
+                                                    const T *__restrict__ val, int rows, int rb, int B, int S,
                                                     int wcols, const unsigned int *__restrict__ c1q,
                                                     const unsigned int *__restrict__ c2q, T *__restrict__ val1,
                                                     unsigned short *__restrict__ col1, unsigned short *__restrict__ lrow)
@@ -244,8 +244,8 @@ __global__ void __launch_bounds__(256) k_bb_scatter(const int *__restrict__ rowp
         for (int s = lane; s < S; s += 64)
             s_cur[w][s] = 0u;
         __builtin_amdgcn_wave_barrier();
-        const int r0 = b << rb_shift;
-        const int r1 = (r0 + (1 << rb_shift)) < rows ? r0 + (1 << rb_shift) : rows;
+        const int r0 = b * rb;
+        const int r1 = (r0 + rb) < rows ? r0 + rb : rows;
         const int e0 = rowptr[r0], e1 = rowptr[r1];
         for (int base = e0; base < e1; base += 64) {
             const int j = base + lane;
@@ -302,7 +302,21 @@ __global__ void __launch_bounds__(256) k_bb_fill16(unsigned short *__restrict__ 
         p[i] = (unsigned short)v;
 }
 
-int g_blk_bin_rows = 2048; /* rows per bin of phase 2 (tuning key 18: 1024, 2048, 4096), read when a layout is built */
+int g_blk_bin_rows = 0; /* rows per bin of phase 2 (tuning key 18: 0 = by the row count, or one of the instantiated sizes), read when a layout is built */
+
+/* Rows per bin.  Phase 2 runs one wave per bin, four waves and 4 RB sizeof(T) bytes of LDS per workgroup: up to 2560 rows
+ * two workgroups share a CU -- 2048 waves at a time on 256 CUs.  A matrix with a few more bins than that pays a second,
+ * nearly empty round (SparseBench 170^3 in bins of 2048 rows: 2399 bins), so the bins are sized to fill whole rounds. */
+int choose_bin_rows(int rows)
+{
+    if (g_blk_bin_rows)
+        return g_blk_bin_rows;
+    const int64_t slots = 2048, rb_max = 2560;
+    const int64_t rounds = (rows + slots * rb_max - 1) / (slots * rb_max);
+    int64_t rb = (rows + slots * rounds - 1) / (slots * rounds);
+    rb = (rb + 255) / 256 * 256;
+    return (int)(rb < 1024 ? 1024 : rb > rb_max ? rb_max : rb);
+}
 
 } // namespace
 
@@ -315,7 +329,7 @@ extern "C" void spmv_blocked_free(spmv_dev_blocked *d)
 
 extern "C" void spmvk_blocked_set_wgs(int bin_rows)
 {
-    if (bin_rows == 1024 || bin_rows == 2048 || bin_rows == 4096)
+    if (bin_rows == 0 || (bin_rows >= 1024 && bin_rows <= 2560 && bin_rows % 256 == 0))
         g_blk_bin_rows = bin_rows;
 }
 
@@ -349,8 +363,7 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
         wcols = (wcols + E - 1) / E * E;
         S = (cols + wcols - 1) / wcols;
     }
-    const int RB = g_blk_bin_rows;
-    const int rb_shift = RB == 1024 ? 10 : RB == 2048 ? 11 : 12;
+    const int RB = choose_bin_rows(rows);
     const int B = (rows + RB - 1) / RB;
     const size_t ncells = (size_t)S * (size_t)B;
     if (S > BB_MAX_STRIPES || ncells > ((size_t)1 << 24))
@@ -377,7 +390,7 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     BKCHK(hipMalloc((void **)&d_cnt, ncells * sizeof(int)));
     BKCHK(hipMemsetAsync(d_cnt, 0, ncells * sizeof(int), st));
     hipLaunchKernelGGL(k_bb_count, dim3(nnz < 256 * 4096 ? (unsigned int)((nnz + 255) / 256) : 4096u), dim3(256), 0, st, d_rowptr,
-                       d_col, rows, (int)nnz, wcols, rb_shift, B, d_cnt);
+                       d_col, rows, (int)nnz, wcols, RB, B, d_cnt);
     BKCHK(hipGetLastError());
     BKCHK(hipMemcpyAsync(h_cnt, d_cnt, ncells * sizeof(int), hipMemcpyDeviceToHost, st));
     BKCHK(hipStreamSynchronize(st));
@@ -480,10 +493,10 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
         const int grid_b = B < 4 * 4096 ? (B + 3) / 4 : 4096;
         if (elem_size == 8)
             hipLaunchKernelGGL(k_bb_scatter<double>, dim3(grid_b), dim3(256), 0, st, d_rowptr, d_col, (const double *)d_val, rows,
-                               rb_shift, B, S, wcols, d_c1q, d_c2q, (double *)d.val1, d.col1, d.lrow);
+                               RB, B, S, wcols, d_c1q, d_c2q, (double *)d.val1, d.col1, d.lrow);
         else
             hipLaunchKernelGGL(k_bb_scatter<float>, dim3(grid_b), dim3(256), 0, st, d_rowptr, d_col, (const float *)d_val, rows,
-                               rb_shift, B, S, wcols, d_c1q, d_c2q, (float *)d.val1, d.col1, d.lrow);
+                               RB, B, S, wcols, d_c1q, d_c2q, (float *)d.val1, d.col1, d.lrow);
     }
     hipLaunchKernelGGL(k_bb_dest, dim3((unsigned int)((ncells + 255) / 256)), dim3(256), 0, st, d_c1q, d_c2q, ncells, d.dest4);
     BKCHK(hipGetLastError());
@@ -503,17 +516,28 @@ out:
     return rc;
 }
 
+/* U = 2 windows in flight per wave in both phases: 1 to 8 differ by less than the boxes do (SparseBench 170^3: 160-164 us with 2,
+ * 165-170 with 4, 180 with one window in phase 2; profiles/r03_blocked_prefetch_depth.log): 16 and 8 waves per CU hide the
+ * latency, the memory system is what both phases wait for */
 template <typename T> static void launch_blocked(const spmv_dev_blocked *d, const void *x, void *y, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_blk_products<T, 4>), dim3(d->n_wg), dim3(BB_P1_WAVES * 64), 0, st, d->wg, (const T *)d->val1, d->col1,
+    hipLaunchKernelGGL((k_blk_products<T, 2>), dim3(d->n_wg), dim3(BB_P1_WAVES * 64), 0, st, d->wg, (const T *)d->val1, d->col1,
                        d->dest4, (const T *)x, d->cols, d->wcols, (T *)d->prod);
     const dim3 g2((d->B + 3) / 4);
-    if (d->RB == 1024)
-        hipLaunchKernelGGL((k_blk_bins<T, 4, 1024>), g2, dim3(256), 0, st, d->bw, (const T *)d->prod, d->lrow, d->rows, d->B, (T *)y);
-    else if (d->RB == 2048)
-        hipLaunchKernelGGL((k_blk_bins<T, 4, 2048>), g2, dim3(256), 0, st, d->bw, (const T *)d->prod, d->lrow, d->rows, d->B, (T *)y);
-    else
-        hipLaunchKernelGGL((k_blk_bins<T, 4, 4096>), g2, dim3(256), 0, st, d->bw, (const T *)d->prod, d->lrow, d->rows, d->B, (T *)y);
+#define BLK_BINS(RB_)                                                                                                          \
+    case RB_:                                                                                                                  \
+        hipLaunchKernelGGL((k_blk_bins<T, 2, RB_>), g2, dim3(256), 0, st, d->bw, (const T *)d->prod, d->lrow, d->rows, d->B, (T *)y); \
+        break
+    switch (d->RB) {
+        BLK_BINS(1024);
+        BLK_BINS(1280);
+        BLK_BINS(1536);
+        BLK_BINS(1792);
+        BLK_BINS(2048);
+        BLK_BINS(2304);
+        BLK_BINS(2560);
+    }
+#undef BLK_BINS
 }
 
 extern "C" int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *stream)

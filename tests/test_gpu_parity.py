@@ -1338,7 +1338,7 @@ def test_blocked_plan(pkg, backend, oracle):
     rs, ci, a = matgen.random_csr(104, 50001, 2_000_000, 7, np.float64, empty_frac=0.05, spread=0.9)
     x = rng.standard_normal(int(ci.max()))
     try:
-        for bin_rows in (1024, 4096, 2048):
+        for bin_rows in (1024, 2560, 1792):
             backend.set_tuning(18, bin_rows)
             m = backend.matrix(a, rs, ci, 50001)
             m.set_plan(pkg.PLAN_BLOCKED, 0)
@@ -1346,7 +1346,7 @@ def test_blocked_plan(pkg, backend, oracle):
                               np.float64, "bins of %d rows" % bin_rows, CSR)
             m.close()
     finally:
-        backend.set_tuning(18, 2048)
+        backend.set_tuning(18, 0)
     # more columns than 2048 stripes of 160 KB hold
     rs, ci, a = matgen.random_csr(103, 3000, 45_000_000, 30, np.float64, sort_cols=False)
     m = backend.matrix(a, rs, ci, 3000)
