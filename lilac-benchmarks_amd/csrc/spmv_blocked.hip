@@ -35,6 +35,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -284,16 +285,18 @@ __global__ void __launch_bounds__(256) k_bb_scatter(const int *__restrict__ rowp
     }
 }
 
-/* thread per cell: the destination of each of its groups of four products */
+/* thread per cell: the destination of each of its groups of four products; what follows the last cell of a stripe up to
+ * the window boundary goes to the spare group */
 __global__ void __launch_bounds__(256) k_bb_dest(const unsigned int *__restrict__ c1q, const unsigned int *__restrict__ c2q,
-                                                 size_t ncells, unsigned int *__restrict__ dest4)
+                                                 const int *__restrict__ padded, size_t ncells, unsigned int spare,
+                                                 unsigned int *__restrict__ dest4)
 {
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= ncells)
         return;
-    const unsigned int a = c1q[id], n = c1q[id + 1] - a, d = c2q[id];
+    const unsigned int a = c1q[id], n = c1q[id + 1] - a, d = c2q[id], real = (unsigned int)padded[id] / 4u;
     for (unsigned int q = 0; q < n; ++q)
-        dest4[a + q] = d + q;
+        dest4[a + q] = q < real ? d + q : spare;
 }
 
 __global__ void __launch_bounds__(256) k_bb_fill16(unsigned short *__restrict__ p, size_t n, int v)
@@ -335,11 +338,11 @@ extern "C" void spmvk_blocked_set_wgs(int bin_rows)
 
 /*
  * Builds the BLOCKED layout of a device-resident CSR block (d_rowptr 0-based and local, d_col 1-based).  0; -2: not
- * representable (more than 2048 column stripes, more than 2^24 cells, a stream beyond 2^31 entries); -3: out of memory;
- * -1: a HIP error.
+ * representable (more than 2048 column stripes, more than 2^24 cells, a stream beyond 2^31 entries) or, for an automatic
+ * choice, not suited (see below); -3: out of memory; -1: a HIP error.
  */
 extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, const void *d_val, int rows, int cols,
-                                         int elem_size, int64_t nnz, void *stream, spmv_dev_blocked *out)
+                                         int elem_size, int64_t nnz, int auto_choice, void *stream, spmv_dev_blocked *out)
 {
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
@@ -394,29 +397,22 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     BKCHK(hipGetLastError());
     BKCHK(hipMemcpyAsync(h_cnt, d_cnt, ncells * sizeof(int), hipMemcpyDeviceToHost, st));
     BKCHK(hipStreamSynchronize(st));
-    /* ---- the two orders.  Phase 1: stripe-major, cells padded to fours, a stripe's last cell to the window; phase 2:
+    /* ---- the two orders.  Phase 1: stripe-major, cells padded to fours, a stripe to the window; phase 2:
      * bin-major with the same padded cells, a bin's end padded to the window (slots nobody writes: they stay zero) */
     {
         int64_t p = 0, total = 0;
         for (int s = 0; s < S; ++s) {
             stripe_w0[s] = p / BB_WIN;
-            long long last = -1;
             for (int b = 0; b < B; ++b) {
                 const size_t id = (size_t)s * B + b;
                 total += h_cnt[id];
                 h_cnt[id] = (h_cnt[id] + 3) & ~3; /* from here on: the padded size */
                 h_c1q[id] = (unsigned int)(p / 4);
                 p += h_cnt[id];
-                if (h_cnt[id])
-                    last = b;
             }
-            const int64_t q = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
-            if (q != p && last >= 0) {
-                h_cnt[(size_t)s * B + last] += (int)(q - p);
-                for (long long b = last + 1; b < B; ++b)
-                    h_c1q[(size_t)s * B + b] = (unsigned int)(q / 4);
-                p = q;
-            }
+            /* the stripe ends on a window boundary: the groups of four behind its last cell are pads whose products (0 x 0)
+             * go to the spare group behind phase 2's stream (k_bb_dest), not into a bin */
+            p = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
             if (p > ((int64_t)1 << 31) - 4 * BB_WIN) {
                 rc = -2;
                 goto out;
@@ -446,6 +442,32 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
         }
         h_bw[B] = (int)(p / BB_WIN);
         n2 = p;
+    }
+    /*
+     * An automatic choice is taken back when the plan cannot pay off (spmv_plan_choose nominates by shape alone):
+     *  - the columns are LOCAL to the rows (banded): the CSR kernels' gathers of x hit in cache and nothing is gained for the
+     *    products' extra trip through memory.  Seen from here: far fewer cells hold entries than scattered columns
+     *    would fill (a cell of mean m entries is empty with probability exp(-m));
+     *  - one bin holds half as much again as the mean (dense rows): phase 2 lasts as long as its heaviest bin's wave.
+     */
+    if (auto_choice) {
+        size_t nonempty = 0;
+        int64_t max_bin = 0;
+        for (int b = 0; b < B; ++b) {
+            int64_t e = 0;
+            for (int s = 0; s < S; ++s) {
+                const int c = h_cnt[(size_t)s * B + b];
+                nonempty += c != 0;
+                e += c;
+            }
+            max_bin = e > max_bin ? e : max_bin;
+        }
+        const double mean_cell = (double)nnz / (double)ncells;
+        const double expected = (double)ncells * (1.0 - exp(-mean_cell));
+        if ((double)nonempty < 0.6 * expected || (double)max_bin > 1.5 * (double)n2 / (double)B + 2048.0) {
+            rc = -2;
+            goto out;
+        }
     }
     /* ---- phase 1's workgroups: one per stripe; a stripe with more than 5/4 of the mean share is cut */
     {
@@ -477,7 +499,7 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     BKCHK(hipMalloc(&d.val1, (size_t)n1 * (size_t)elem_size));
     BKCHK(hipMalloc((void **)&d.col1, (size_t)n1 * sizeof(unsigned short)));
     BKCHK(hipMalloc((void **)&d.dest4, (size_t)n1 / 4 * sizeof(unsigned int)));
-    BKCHK(hipMalloc(&d.prod, (size_t)n2 * (size_t)elem_size));
+    BKCHK(hipMalloc(&d.prod, ((size_t)n2 + 4) * (size_t)elem_size)); /* + the spare group */
     BKCHK(hipMalloc((void **)&d.lrow, (size_t)n2 * sizeof(unsigned short)));
     BKCHK(hipMalloc((void **)&d.wg, ((size_t)n_wg + 1) * 3 * sizeof(int)));
     BKCHK(hipMalloc((void **)&d.bw, ((size_t)B + 1) * sizeof(int)));
@@ -486,7 +508,7 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     BKCHK(hipMemcpyAsync(d.wg, h_wg, (size_t)n_wg * 3 * sizeof(int), hipMemcpyHostToDevice, st));
     BKCHK(hipMemcpyAsync(d.bw, h_bw, ((size_t)B + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     BKCHK(hipMemsetAsync(d.val1, 0, (size_t)n1 * (size_t)elem_size, st));
-    BKCHK(hipMemsetAsync(d.prod, 0, (size_t)n2 * (size_t)elem_size, st));
+    BKCHK(hipMemsetAsync(d.prod, 0, ((size_t)n2 + 4) * (size_t)elem_size, st));
     BKCHK(hipMemsetAsync(d.lrow, 0, (size_t)n2 * sizeof(unsigned short), st));
     hipLaunchKernelGGL(k_bb_fill16, dim3(1024), dim3(256), 0, st, d.col1, (size_t)n1, W - 1); /* pads: times the zero column */
     {
@@ -498,7 +520,9 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
             hipLaunchKernelGGL(k_bb_scatter<float>, dim3(grid_b), dim3(256), 0, st, d_rowptr, d_col, (const float *)d_val, rows,
                                RB, B, S, wcols, d_c1q, d_c2q, (float *)d.val1, d.col1, d.lrow);
     }
-    hipLaunchKernelGGL(k_bb_dest, dim3((unsigned int)((ncells + 255) / 256)), dim3(256), 0, st, d_c1q, d_c2q, ncells, d.dest4);
+    BKCHK(hipMemcpyAsync(d_cnt, h_cnt, ncells * sizeof(int), hipMemcpyHostToDevice, st)); /* the padded sizes */
+    hipLaunchKernelGGL(k_bb_dest, dim3((unsigned int)((ncells + 255) / 256)), dim3(256), 0, st, d_c1q, d_c2q, d_cnt, ncells,
+                       (unsigned int)(n2 / 4), d.dest4);
     BKCHK(hipGetLastError());
     BKCHK(hipStreamSynchronize(st));
     d.elem = elem_size, d.rows = rows, d.cols = cols, d.nnz = nnz, d.S = S, d.wcols = wcols, d.W = W, d.RB = RB, d.B = B;

@@ -690,11 +690,11 @@ static int ensure_striped(spmv_hip_matrix *m, const void *host_a, const int *hos
 }
 
 /* Builds the BLOCKED layout from the device's CSR copy (spmv_blocked.hip): 0, -2 not representable, -3 no memory, -1 error */
-static int ensure_blocked(spmv_hip_matrix *m)
+static int ensure_blocked(spmv_hip_matrix *m, bool auto_choice)
 {
     if (m->have_blocked)
         return 0;
-    int rc = spmv_blocked_build_device(m->d_rowptr, m->d_col, m->d_val, m->rows, m->cols, m->elem, m->nnz,
+    int rc = spmv_blocked_build_device(m->d_rowptr, m->d_col, m->d_val, m->rows, m->cols, m->elem, m->nnz, auto_choice ? 1 : 0,
                                        g_dev[m->device].stream, &m->db);
     if (rc == 0 && take_injected_oom()) {
         spmv_blocked_free(&m->db);
@@ -702,7 +702,7 @@ static int ensure_blocked(spmv_hip_matrix *m)
     }
     m->blocked_rc = rc;
     if (rc == -2)
-        spmv_set_error("matrix not representable in the BLOCKED layout (more than 2048 column stripes or 2^24 cells)");
+        spmv_set_error("matrix not representable in the BLOCKED layout (more than 2048 column stripes or 2^24 cells) or not suited to it");
     else if (rc == -3)
         spmv_set_error("out of memory for the BLOCKED layout");
     if (rc)
@@ -868,12 +868,14 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
         }
     }
     if (m->plan == SPMV_HIP_PLAN_BLOCKED) {
-        int rc = ensure_blocked(m);
+        int rc = ensure_blocked(m, true);
         if (rc == -2 || rc == -3) {
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
         } else if (rc) {
             FAIL();
+        } else {
+            m->param = m->db.wcols;
         }
     }
     if (m->plan == SPMV_HIP_PLAN_BINNED && ensure_bins(m))
@@ -904,7 +906,7 @@ int spmv_hip_matrix_refresh_values(spmv_hip_matrix *m, const void *a, const int 
         free_relayouts(m);
         int rc = 0;
         if (was_blocked)
-            rc = ensure_blocked(m);
+            rc = ensure_blocked(m, false);
         else if (was_striped)
             rc = ensure_striped(m, colidx ? a : nullptr, colidx, m->first, false);
         else if (was_tiled)
@@ -940,15 +942,19 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
         }
-        if (m->plan == SPMV_HIP_PLAN_BLOCKED && ensure_blocked(m)) {
-            if (m->blocked_rc != -2 && m->blocked_rc != -3)
-                return -1;
-            m->plan = SPMV_HIP_PLAN_STREAM;
-            m->param = SPMV_STREAM_CAP;
+        if (m->plan == SPMV_HIP_PLAN_BLOCKED) {
+            if (ensure_blocked(m, true)) {
+                if (m->blocked_rc != -2 && m->blocked_rc != -3)
+                    return -1;
+                m->plan = SPMV_HIP_PLAN_STREAM;
+                m->param = SPMV_STREAM_CAP;
+            } else {
+                m->param = m->db.wcols;
+            }
         }
         break;
     case SPMV_HIP_PLAN_BLOCKED:
-        if (ensure_blocked(m))
+        if (ensure_blocked(m, false))
             return -1;
         m->plan = plan;
         m->param = m->db.wcols;

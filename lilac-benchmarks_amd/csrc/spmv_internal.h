@@ -235,8 +235,9 @@ typedef struct spmv_dev_blocked {
     int64_t nnz, n1, n2;
     size_t bytes;
 } spmv_dev_blocked;
+/* auto_choice: decline (-2) a matrix the plan does not suit (columns local to the rows, one bin far heavier than the rest) */
 int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, const void *d_val, int rows, int cols, int elem_size,
-                              int64_t nnz, void *stream, spmv_dev_blocked *out);
+                              int64_t nnz, int auto_choice, void *stream, spmv_dev_blocked *out);
 void spmv_blocked_free(spmv_dev_blocked *d);
 int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *stream);
 

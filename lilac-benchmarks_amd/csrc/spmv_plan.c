@@ -373,6 +373,20 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
         return;
     }
     /*
+     * BLOCKED (two phases over (column stripe, row bin) cells: x in LDS, products binned by row, csrc/spmv_blocked.hip) when
+     * x is beyond what gathers well -- an XCD's L2 holds 4 MB -- and the rows are too short for STRIPED.  SparseBench n^3
+     * against STREAM (profiles/r03_dispatch_audit.log): 170^3 (x = 39 MB, 4.9 entries per row) 371 us -> BLOCKED, 160^3 123
+     * against 300, 140^3 88 / 187, 120^3 65 / 107, 100^3 (8 MB) 44 / 52; 2 M rows x 16 scattered entries 169 / 482; but
+     * 512 000 rows x 4 (x = 4 MB) 41 / 30 the other way.  Whether the columns really are scattered -- a banded matrix of this
+     * shape gathers from cache: 2.5 M rows x 5, 74 / 30 -- and the rows even -- an R-MAT graph piles its hubs into one bin:
+     * 2^19 vertices 914 / 56 -- is for the builder to see (it counts the entries of every cell) and to decline.
+     */
+    if ((int64_t)cols * elem_size >= 7864320 && st->nnz >= 4000000 && st->rows >= 262144 && st->max_len <= 65536) {
+        *plan = SPMV_HIP_PLAN_BLOCKED;
+        *param = 0;
+        return;
+    }
+    /*
      * Still small (a few microseconds of kernel) and the rows are alike: lane groups straight from
      * global memory beat the two-phase STREAM kernel by 10-15 % (NPB class W 3.7 vs 4.3 us, class A
      * 8.3 vs 9.9 us).  Not for skewed rows: on R-MAT 2^14 a 16-lane group per row takes 27 us where

@@ -1355,6 +1355,55 @@ def test_blocked_plan(pkg, backend, oracle):
     m.close()
 
 
+def test_auto_takes_blocked_for_scattered_columns_only(pkg, backend, oracle):
+    """spmv_plan_choose nominates BLOCKED by shape (x of 16 MB and more, rows too short for STRIPED); the builder, which
+    counts the entries of every (stripe, bin) cell, takes the nomination back when the columns are local to the rows (the CSR
+    kernels' gathers hit in cache then) or one bin is far heavier than the rest.  Both ways through the automatic choice,
+    results against the oracle."""
+    rng = np.random.default_rng(140)
+    rows = 130 ** 3
+    sb = pkg.callers.sb_generate(130)  # x = 17.6 MB, ~4.9 uniformly scattered columns per row (the C generator: seconds)
+    rs, ci, a = (np.array(v) for v in sb.arrays())
+    pkg.callers.free(sb)
+    x = rng.standard_normal(rows)
+    m = backend.matrix(a, rs, ci, rows)
+    try:
+        inf = m.info()
+        assert inf["plan"] == pkg.PLAN_BLOCKED and inf["n_launches"] == 2, inf
+        assert_close_rows(m.spmv_host(x), oracle.spmv(a, x, rs, ci, rows), oracle.absum(a, x, rs, ci, rows), np.diff(rs), np.float64,
+                          "scattered", CSR)
+    finally:
+        m.close()
+    # the same row lengths, the columns within 40 of the diagonal
+    lens = np.diff(rs).astype(np.int64)
+    k = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+    ci_b = ((np.repeat(np.arange(rows, dtype=np.int64), lens) + 3 * k) % rows + 1).astype(np.int32)
+    m = backend.matrix(a, rs, ci_b, rows)
+    try:
+        assert m.info()["plan"] == pkg.PLAN_STREAM, m.info()
+        assert_close_rows(m.spmv_host(x), oracle.spmv(a, x, rs, ci_b, rows), oracle.absum(a, x, rs, ci_b, rows), np.diff(rs),
+                          np.float64, "banded", CSR)
+        m.set_plan(pkg.PLAN_BLOCKED, 0)  # asked for by name it is built all the same
+        assert_close_rows(m.spmv_host(x), oracle.spmv(a, x, rs, ci_b, rows), oracle.absum(a, x, rs, ci_b, rows), np.diff(rs),
+                          np.float64, "banded, BLOCKED by name", CSR)
+    finally:
+        m.close()
+    # scattered columns, one row with 600 000 entries more: its bin would run long after the others
+    r0, extra = rows // 3, 600_000
+    p = int(rs[r0 + 1]) - 1
+    ci2 = np.concatenate([ci[:p], rng.integers(1, rows + 1, extra).astype(np.int32), ci[p:]])
+    a2 = np.concatenate([a[:p], rng.standard_normal(extra), a[p:]])
+    rs2 = rs.copy()
+    rs2[r0 + 1:] += extra
+    m = backend.matrix(a2, rs2, ci2, rows)
+    try:
+        assert m.info()["plan"] != pkg.PLAN_BLOCKED, m.info()
+        assert_close_rows(m.spmv_host(x), oracle.spmv(a2, x, rs2, ci2, rows), oracle.absum(a2, x, rs2, ci2, rows), np.diff(rs2),
+                          np.float64, "one heavy row", CSR)
+    finally:
+        m.close()
+
+
 def test_no_room_for_the_second_copy_is_not_fatal(pkg):
     """The re-laid-out copy of a matrix (STRIPED, TILED) is an optimisation next to the CSR copy: when the device has
     no memory for it, an automatic choice falls back to the CSR kernels and the product is still right; only asking

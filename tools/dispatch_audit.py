@@ -18,7 +18,7 @@ def main():
     pkg = pkgload.load_package()
     be = pkg.Backend()
     cand = [("striped", pkg.PLAN_STRIPED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec16", pkg.PLAN_VECTOR, 16),
-            ("vec64", pkg.PLAN_VECTOR, 64), ("vec4", pkg.PLAN_VECTOR, 4)]
+            ("vec64", pkg.PLAN_VECTOR, 64), ("vec4", pkg.PLAN_VECTOR, 4), ("blocked", pkg.PLAN_BLOCKED, 0)]
     print("%8s %6s %9s | %-8s %8s | best %-8s %8s | %s" % ("rows", "mean", "nnz", "auto", "us", "plan", "us", "all"))
     worst = []
     for rows in (2000, 8000, 32000, 128000, 512000, 2000000):
@@ -72,7 +72,7 @@ def main():
     # other structures: columns local to the rows (banded), heavy-tailed row lengths, R-MAT graphs
     rng = np.random.default_rng(11)
     extra = []
-    for rows, mean in ((50000, 60), (200000, 40), (1000000, 12)):
+    for rows, mean in ((50000, 60), (200000, 40), (1000000, 12), (2500000, 5)):
         lens = rng.poisson(mean, rows).astype(np.int64)
         start = np.cumsum(lens) - lens
         k = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(start, lens)
@@ -84,6 +84,17 @@ def main():
         extra.append(("pareto %d" % rows,) + matgen.csr_from_lengths(rng, [int(v) for v in lens], rows, dtype))
     for sc in (15, 17, 19):
         extra.append(("rmat%d" % sc,) + matgen.rmat_graph(20, sc, 16, dtype, values="normal"))
+    # SparseBench-like: short rows, uniformly scattered columns, x from 8 to 33 MB (BLOCKED's ground from 16 MB on)
+    for size in (100, 120, 128, 140, 160):
+        sb = pkg.callers.sb_generate(size)
+        rs, ci, a = (np.array(v) for v in sb.arrays())
+        pkg.callers.free(sb)
+        extra.append(("sparsebench %d^3" % size, rs, ci, a.astype(dtype)))
+    for rows, mean in ((3000000, 12), (2400000, 2)):  # columns drawn uniformly, unsorted, repeats allowed
+        lens = np.maximum(1, rng.poisson(mean, rows)).astype(np.int64)
+        rs = np.concatenate(([1], 1 + np.cumsum(lens))).astype(np.int32)
+        ci = rng.integers(1, rows + 1, int(lens.sum())).astype(np.int32)
+        extra.append(("scattered %dx%d" % (rows, mean), rs, ci, rng.standard_normal(ci.size).astype(dtype)))
     for name, rs, ci, a in extra:
         rows = rs.size - 1
         dm = be.matrix(a, rs, ci, rows)
