@@ -153,6 +153,9 @@ def other_configs(pkg, be, np, line):
     ms = dm.time_device(dx, dy, 20) / 20
     y = be.d2h(np.empty(sb.rows), dy)
     check_rows(np, a, rs, ci, x, y, "sparsebench 170 kernel")
+    dm.set_plan(pkg.PLAN_STREAM, 0)  # the CSR row-segment kernel on the same matrix, for the record
+    dm.time_device(dx, dy, 3)
+    ms_stream = dm.time_device(dx, dy, 10) / 10
     dm.close(), be.free(dx), be.free(dy)
     be.reset_stats()
     yy = np.empty(sb.rows)
@@ -164,8 +167,9 @@ def other_configs(pkg, be, np, line):
     check_rows(np, a, rs, ci, x, yy, "sparsebench 170 through the ABI")
     be.release()
     line["sparsebench_170"] = {
-        "rows": sb.rows, "nnz": int(sb.nnz), "plan": pkg.abi.PLAN_NAMES[inf["plan"]], "kernel_us": round(ms * 1e3, 2),
-        "frac": round(inf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "rows": sb.rows, "nnz": int(sb.nnz), "plan": pkg.abi.PLAN_NAMES[inf["plan"]], "launches_per_product": inf["n_launches"],
+        "kernel_us": round(ms * 1e3, 2), "frac": round(inf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "kernel_us_stream_plan": round(ms_stream * 1e3, 2),
         "algorithmic_bytes_per_launch": inf["algorithmic_bytes"], "abi_ms_per_call": round(abi_ms, 3),
         "abi_moves": "x and y, 39 MB each, host <-> GPU on every call (random.f:32,72)", "setup_s": round(time.time() - t0, 1),
     }

@@ -406,7 +406,7 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
             for (int b = 0; b < B; ++b) {
                 const size_t id = (size_t)s * B + b;
                 total += h_cnt[id];
-                h_cnt[id] = (h_cnt[id] + 3) & ~3; /* from here on: the padded size */
+                h_cnt[id] = (h_cnt[id] + 3) & ~3; /* from here on: the padded size (to eights: SparseBench 170^3 146 us against 144) */
                 h_c1q[id] = (unsigned int)(p / 4);
                 p += h_cnt[id];
             }

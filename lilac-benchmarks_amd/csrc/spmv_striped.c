@@ -409,7 +409,7 @@ static void cut_rows(const uint32_t *wgt, int rows, int n, int wave_rows, const 
  * the cheapest most expensive workgroup wins, the larger group count on a tie.  Class C: 5 groups of 2 stripes (51-52 row
  * blocks each); all of class D: 2 groups of 46 stripes.
  */
-#define STRIPE_RESTAGE_ENTRIES 256 /* a change of stripe, in entries of a wave's stream (1.5 us at 174 entries per us) */
+#define STRIPE_RESTAGE_ENTRIES 256 /* a change of stripe behind a long tile, in entries of a wave's stream (1.5 us at 174 entries per us) */
 #define STRIPE_PARTIAL_FACTOR 2.5  /* a group's partial sums cost 2.5 x their bytes: k_group_sum's own time is in it */
 static double geometry_cost(int S, int cand, int nb_min, int target, int wpb, int64_t nnz, int64_t sub, int rows, int elem)
 {
@@ -434,7 +434,11 @@ static double geometry_cost(int S, int cand, int nb_min, int target, int wpb, in
             continue;
         const double tile = per_stripe / ((double)nb * wpb);
         const double padded = tile + 0.5 * (double)sub; /* a tile ends somewhere inside its last sub-window */
-        const double c = st * (padded + STRIPE_RESTAGE_ENTRIES);
+        /* a change of stripe hides behind the wave's stream when that is long; behind a tile of a few hundred entries it
+         * shows in full: 128 000 rows x 16 (8 stripes) 12.6 / 15.1 / 18.3 us with 1 / 2 / 4 stripes per group, 512 000 x 64
+         * (32 stripes) 84 / 90 / 110 us with 4 / 8 / 16 (profiles/r03_shapebench_small_shapes.log) */
+        const double restage = STRIPE_RESTAGE_ENTRIES * (1.0 + (tile > 1024.0 ? 1024.0 / tile : 1.0));
+        const double c = st * (padded + restage);
         cost = c > cost ? c : cost;
     }
     if (cand > 1) /* the partial sums, in entries (elem + 2 bytes each), per wave; written, read again, and added by a second launch */

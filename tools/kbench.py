@@ -39,6 +39,9 @@ def build_case(pkg, name, dtype):
         m = pkg.callers.sb_generate(int(name[2:]))
         rs, ci, a = m.arrays()
         return rs, ci, a.astype(dtype), m
+    if name.startswith("npb:"):  # tools/dispatch_audit.py's grid: npb:<rows>x<mean>, NPB-like row lengths, scattered columns
+        rows, mean = (int(v) for v in name[4:].split("x"))
+        return matgen.npb_like(7, rows, mean, dtype) + (None,)
     if name.startswith("rmat"):
         return matgen.rmat_graph(20, int(name[4:]), 16, dtype, values="normal") + (None,)
     if name.startswith("grid"):

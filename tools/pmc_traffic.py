@@ -48,7 +48,7 @@ def workloads(values):
 
 
 def short(name):
-    for k in ("k_striped", "k_group_sum", "k_tiled", "k_stream", "k_long"):
+    for k in ("k_striped", "k_group_sum", "k_tiled", "k_stream", "k_long", "k_blk_products", "k_blk_bins"):
         if k in name:
             return k
     return None
