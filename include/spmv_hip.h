@@ -32,10 +32,11 @@ enum {
     SPMV_HIP_PLAN_STRIPED = 6, /* 2-D: a workgroup = (group of column stripes, row block); one stripe */
                                /* of x in LDS at a time, row sums carried in registers across the  */
                                /* group, one partial sum per (group, row), added in group order     */
-    SPMV_HIP_PLAN_BLOCKED = 7  /* column blocks of 2 MB of x, entries block-major, XCD c % 8 works on   */
-                               /* block c (its gathers hit its own L2); one sum per (row, block)       */
-                               /* segment, added per row in block order: for short rows with scattered */
-                               /* columns over a long x (SparseBench), where STRIPED has nothing to gain */
+    SPMV_HIP_PLAN_BLOCKED = 7  /* two phases over (column stripe, row bin) cells: a workgroup keeps a    */
+                               /* stripe of x in LDS and writes the PRODUCTS binned by row; one wave per */
+                               /* bin adds them in LDS.  No gathers from memory: for short rows with     */
+                               /* scattered columns over a long x (SparseBench), where the CSR kernels   */
+                               /* fetch a 64-byte line per entry and STRIPED has nothing to gain         */
 };
 
 /* Opaque device-resident matrix (CSR block + execution plan) on one GPU. */
@@ -178,7 +179,7 @@ int spmv_hip_synchronize(int device);
  * bytes per stripe, workgroups aimed for); 5 register sets of k_tiled; 9, 11, 12 STRIPED geometry (workgroups aimed for,
  * stripe groups, most rows per wave range; 0 = choose); 15 STRIPED kernel shape (0 = chosen per matrix, 1 = 16 waves x
  * 128 KiB of x, 2 = 8 waves x 64 KiB); 17 who converts to STRIPED (0 = the GPU, from the CSR copy in HBM, the host threads
- * when it must; 1 = the host; 2 = the GPU or fail); 18 BLOCKED phase-1 workgroups per XCD; 19 STRIPED: per mille of weight
+ * when it must; 1 = the host; 2 = the GPU or fail); 18 BLOCKED: rows per bin of layouts built from now on (0 = sized to fill whole rounds of phase 2; 1024 ... 2560 in steps of 256); 19 STRIPED: per mille of weight
  * moved from the workgroups of even XCDs to those of odd ones (default 0: measured, within noise); 20 STRIPED: the packed
  * stream is loaded non-temporally 0 = when it exceeds the Infinity Cache, 1 = always, 2 = never.  Diagnostics (ablation bits, clock stamps, fault injection) are not in this
  * library: they live in the debug build, include/spmv_hip_debug.h. */

@@ -1347,6 +1347,25 @@ def test_blocked_plan(pkg, backend, oracle):
             m.close()
     finally:
         backend.set_tuning(18, 0)
+    # two fresh processes: the same bits (the layout is counted, the LDS adds a given address pattern in a fixed order)
+    code = """
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, pkgload
+pkg = pkgload.load_package(); be = pkg.Backend()
+sb = pkg.callers.sb_generate(60)
+rs, ci, a = (np.array(v) for v in sb.arrays())
+m = be.matrix(a, rs, ci, sb.rows)
+m.set_plan(pkg.PLAN_BLOCKED, 0)
+x = np.random.default_rng(5).standard_normal(sb.rows)
+h = hashlib.sha256()
+for _ in range(20):
+    h.update(m.spmv_host(x).tobytes())
+print("BLK", h.hexdigest())
+m.close(); be.release()
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    d1, d2 = (_run_py(code, {}).split()[-1] for _ in range(2))
+    assert d1 == d2 and len(d1) == 64
     # more columns than 2048 stripes of 160 KB hold
     rs, ci, a = matgen.random_csr(103, 3000, 45_000_000, 30, np.float64, sort_cols=False)
     m = backend.matrix(a, rs, ci, 3000)
