@@ -153,13 +153,16 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ bw, co
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E, NV = 4 / E;
     typedef unsigned short rows_t __attribute__((ext_vector_type(E)));
-    __shared__ __attribute__((aligned(16))) T s_y[4][RB];
+    /* the sums are doubles for both precisions: ds_add_f32 runs at a fraction of ds_add_f64's rate on gfx950 (SparseBench
+     * 160^3 in f32: phase 2 114 us with float slices, 25 with these; profiles/r03_blocked_f32_lds_atomics.log).  A float
+     * row is therefore summed in double and rounded once -- closer to the exact sum than any float order, inside the bar */
+    __shared__ __attribute__((aligned(16))) double s_y[4][RB];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + w;
     if (b >= nbins)
         return;
     for (int i = lane; i < RB; i += 64)
-        s_y[w][i] = (T)0;
+        s_y[w][i] = 0.0;
     __builtin_amdgcn_wave_barrier();
     const int a = __builtin_amdgcn_readfirstlane(bw[b]), e = __builtin_amdgcn_readfirstlane(bw[b + 1]);
     if (a < e) {
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ bw, co
                     for (int j = 0; j < NV; ++j)
 #pragma unroll
                         for (int i = 0; i < E; ++i)
-                            unsafeAtomicAdd(&s_y[w][rr[j][i]], q[j][i]);
+                            unsafeAtomicAdd(&s_y[w][rr[j][i]], (double)q[j][i]);
                 }
             }
         }
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ bw, co
     __builtin_amdgcn_wave_barrier();
     const int r0 = b * RB;
     for (int i = lane; i < RB && r0 + i < rows; i += 64)
-        y[r0 + i] = s_y[w][i];
+        y[r0 + i] = (T)s_y[w][i];
 }
 
 /* ---------------------------------------------------------------- the builder */

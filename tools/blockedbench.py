@@ -9,13 +9,15 @@ import numpy as np  # noqa: E402
 import pkgload  # noqa: E402
 pkg = pkgload.load_package()
 be = pkg.Backend()
-sizes = [int(v) for v in sys.argv[1:]] or [170, 100]
+dtype = np.float32 if "--f32" in sys.argv else np.float64
+sizes = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [170, 100]
 for size in sizes:
     sb = pkg.callers.sb_generate(size)
     rs, ci, a = sb.arrays()
+    a = a.astype(dtype)
     dm = be.matrix(a, rs, ci, sb.rows)
     inf = dm.info()
-    x = np.random.default_rng(1).standard_normal(inf["cols"] + 2)
+    x = np.random.default_rng(1).standard_normal(inf["cols"] + 2).astype(dtype)
     dx, dy = be.malloc(x.nbytes), be.malloc(sb.rows * 8 + 16)
     be.h2d(dx, x)
     dm.set_plan(pkg.PLAN_STREAM, 0)
