@@ -379,9 +379,11 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
      * against 300, 140^3 88 / 187, 120^3 65 / 107, 100^3 (8 MB) 44 / 52; 2 M rows x 16 scattered entries 169 / 482; but
      * 512 000 rows x 4 (x = 4 MB) 41 / 30 the other way.  Whether the columns really are scattered -- a banded matrix of this
      * shape gathers from cache: 2.5 M rows x 5, 74 / 30 -- and the rows even -- an R-MAT graph piles its hubs into one bin:
-     * 2^19 vertices 914 / 56 -- is for the builder to see (it counts the entries of every cell) and to decline.
+     * 2^19 vertices 914 / 56 -- is for the builder to see (it counts the entries of every cell) and to decline.  In floats the
+     * plan is cheaper still (17 instead of 30 bytes per entry through memory) but so are the gathers (16 elements per line):
+     * 120^3 44 / 70, 100^3 32 / 30: from 1.25 M columns (5 MB) on, against 0.94 M columns (7.5 MB) of doubles.
      */
-    if ((int64_t)cols * elem_size >= 7864320 && st->nnz >= 4000000 && st->rows >= 262144 && st->max_len <= 65536) {
+    if (cols >= (elem_size == 8 ? 983040 : 1310720) && st->nnz >= 4000000 && st->rows >= 262144 && st->max_len <= 65536) {
         *plan = SPMV_HIP_PLAN_BLOCKED;
         *param = 0;
         return;
