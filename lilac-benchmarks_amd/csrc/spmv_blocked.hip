@@ -143,12 +143,15 @@ __global__ void __launch_bounds__(BB_P1_WAVES * 64) k_blk_products(const int *__
 }
 
 /* ---------------------------------------------------------------- phase 2 */
-/* one wave per bin: windows [bw[b], bw[b+1]) of the phase-2 stream, rows [b RB, b RB + RB).  The stream is linear: lane l
- * takes the products j * 64 E + l E .. + E - 1 of a window with its j-th 16-byte load */
+/* One wave per PIECE of the phase-2 stream: windows [pw[i], pw[i+1]), all of bin pb[i] -- rows [b RB, b RB + RB) -- or, for a
+ * bin that holds more than its share (dense rows), a run of its stripes; then ps[i] >= 0 names the slot of the piece's
+ * partial sums and k_blk_join adds a bin's slots in order.  The stream is linear: lane l takes the products
+ * j * 64 E + l E .. + E - 1 of a window with its j-th 16-byte load */
 template <typename T, int U, int RB>
-__global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ bw, const T *__restrict__ prod,
-                                                  const unsigned short *__restrict__ lrow, int rows, int nbins,
-                                                  T *__restrict__ y)
+__global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ pw, const int *__restrict__ pb,
+                                                  const int *__restrict__ ps, const T *__restrict__ prod,
+                                                  const unsigned short *__restrict__ lrow, int rows, int npieces,
+                                                  T *__restrict__ y, double *__restrict__ part)
 {
     using VT = typename Vec16<T>::val_t;
     constexpr int E = Vec16<T>::E, NV = 4 / E;
@@ -158,13 +161,14 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ bw, co
      * row is therefore summed in double and rounded once -- closer to the exact sum than any float order, inside the bar */
     __shared__ __attribute__((aligned(16))) double s_y[4][RB];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + w;
-    if (b >= nbins)
+    const int piece = blockIdx.x * 4 + w;
+    if (piece >= npieces)
         return;
     for (int i = lane; i < RB; i += 64)
         s_y[w][i] = 0.0;
     __builtin_amdgcn_wave_barrier();
-    const int a = __builtin_amdgcn_readfirstlane(bw[b]), e = __builtin_amdgcn_readfirstlane(bw[b + 1]);
+    const int a = __builtin_amdgcn_readfirstlane(pw[piece]), e = __builtin_amdgcn_readfirstlane(pw[piece + 1]);
+    const int b = __builtin_amdgcn_readfirstlane(pb[piece]), slot = __builtin_amdgcn_readfirstlane(ps[piece]);
     if (a < e) {
         VT v[U][NV];
         rows_t r[U][NV];
@@ -201,8 +205,27 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ bw, co
     }
     __builtin_amdgcn_wave_barrier();
     const int r0 = b * RB;
-    for (int i = lane; i < RB && r0 + i < rows; i += 64)
-        y[r0 + i] = (T)s_y[w][i];
+    if (slot < 0) {
+        for (int i = lane; i < RB && r0 + i < rows; i += 64)
+            y[r0 + i] = (T)s_y[w][i];
+    } else {
+        for (int i = lane; i < RB; i += 64)
+            part[(size_t)slot * RB + i] = s_y[w][i];
+    }
+}
+
+/* workgroup per cut bin: jn[3 q] = bin, jn[3 q + 1] = its first slot, jn[3 q + 2] = its slots; added in slot order */
+template <typename T>
+__global__ void __launch_bounds__(256) k_blk_join(const int *__restrict__ jn, const double *__restrict__ part, int rb, int rows,
+                                                  T *__restrict__ y)
+{
+    const int b = jn[3 * blockIdx.x], s0 = jn[3 * blockIdx.x + 1], n = jn[3 * blockIdx.x + 2];
+    for (int i = threadIdx.x; i < rb && b * rb + i < rows; i += 256) {
+        double sum = part[(size_t)s0 * rb + i];
+        for (int k = 1; k < n; ++k)
+            sum = sum + part[(size_t)(s0 + k) * rb + i];
+        y[b * rb + i] = (T)sum;
+    }
 }
 
 /* ---------------------------------------------------------------- the builder */
@@ -329,7 +352,8 @@ int choose_bin_rows(int rows)
 extern "C" void spmv_blocked_free(spmv_dev_blocked *d)
 {
     (void)hipFree(d->val1), (void)hipFree(d->col1), (void)hipFree(d->dest4), (void)hipFree(d->wg);
-    (void)hipFree(d->prod), (void)hipFree(d->lrow), (void)hipFree(d->bw);
+    (void)hipFree(d->prod), (void)hipFree(d->lrow), (void)hipFree(d->pw), (void)hipFree(d->pb), (void)hipFree(d->ps);
+    (void)hipFree(d->jn), (void)hipFree(d->part);
     memset(d, 0, sizeof *d);
 }
 
@@ -375,7 +399,9 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     if (S > BB_MAX_STRIPES || ncells > ((size_t)1 << 24))
         return -2;
 
-    int *d_cnt = nullptr, *h_cnt = nullptr, *h_wg = nullptr, *h_bw = nullptr;
+    int *d_cnt = nullptr, *h_cnt = nullptr, *h_wg = nullptr, *h_pw = nullptr, *h_pb = nullptr, *h_ps = nullptr, *h_jn = nullptr;
+    int64_t *bin_e = nullptr;
+    int n_pieces = 0, n_slots = 0, n_join = 0;
     unsigned int *d_c1q = nullptr, *d_c2q = nullptr, *h_c1q = nullptr, *h_c2q = nullptr;
     int64_t *stripe_w0 = nullptr;
     int64_t n1 = 0, n2 = 0;
@@ -387,8 +413,8 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     h_c1q = (unsigned int *)malloc((ncells + 1) * sizeof(unsigned int));
     h_c2q = (unsigned int *)malloc(ncells * sizeof(unsigned int));
     stripe_w0 = (int64_t *)malloc(((size_t)S + 1) * sizeof(int64_t));
-    h_bw = (int *)malloc(((size_t)B + 1) * sizeof(int));
-    if (!h_cnt || !h_c1q || !h_c2q || !stripe_w0 || !h_bw) {
+    bin_e = (int64_t *)calloc((size_t)B, sizeof(int64_t));
+    if (!h_cnt || !h_c1q || !h_c2q || !stripe_w0 || !bin_e) {
         rc = -3;
         goto out;
     }
@@ -429,47 +455,88 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
             rc = -1;
             goto out;
         }
+        /*
+         * Phase 2's pieces.  A bin is one piece -- one wave -- unless it holds more than its share (dense rows: an R-MAT
+         * graph piles its hubs into the first bins): then it is cut, between stripes, into pieces of about the mean bin,
+         * each padded to the window; their partial sums meet in k_blk_join.
+         */
+        int64_t padded_total = 0;
+        for (int s2 = 0; s2 < S; ++s2)
+            for (int b = 0; b < B; ++b) {
+                bin_e[b] += h_cnt[(size_t)s2 * B + b];
+                padded_total += h_cnt[(size_t)s2 * B + b];
+            }
+        /* the share: a quarter above the mean bin.  More pieces than wave slots are no harm -- workgroups are handed out in
+         * order, the cut (heavy) bins' pieces among the first, and a light bin's wave is gone in no time */
+        const int64_t share = (padded_total / B + 1) * 5 / 4 + 1024;
+        size_t cap_pieces = 0;
+        for (int b = 0; b < B; ++b)
+            cap_pieces += (size_t)(bin_e[b] > share * 6 / 5 ? (bin_e[b] + share - 1) / share : 1);
+        h_pw = (int *)malloc((cap_pieces + 1) * sizeof(int));
+        h_pb = (int *)malloc((cap_pieces + 1) * sizeof(int));
+        h_ps = (int *)malloc((cap_pieces + 1) * sizeof(int));
+        h_jn = (int *)malloc(((size_t)B + 1) * 3 * sizeof(int));
+        if (!h_pw || !h_pb || !h_ps || !h_jn) {
+            rc = -3;
+            goto out;
+        }
         p = 0;
+        int64_t max_piece = 0;
         for (int b = 0; b < B; ++b) {
-            h_bw[b] = (int)(p / BB_WIN);
-            for (int s = 0; s < S; ++s) {
-                const size_t id = (size_t)s * B + b;
+            const int want = (int)(bin_e[b] > share * 6 / 5 ? (bin_e[b] + share - 1) / share : 1);
+            const int64_t per = (bin_e[b] + want - 1) / want;
+            int opened = 1;
+            int64_t acc = 0;
+            h_pw[n_pieces] = (int)(p / BB_WIN), h_pb[n_pieces] = b, h_ps[n_pieces] = want > 1 ? n_slots : -1;
+            if (want > 1)
+                h_jn[3 * n_join] = b, h_jn[3 * n_join + 1] = n_slots;
+            for (int s2 = 0; s2 < S; ++s2) {
+                const size_t id = (size_t)s2 * B + b;
+                if (acc >= per && opened < want && h_cnt[id]) { /* the next piece of this bin starts with this stripe */
+                    max_piece = acc > max_piece ? acc : max_piece;
+                    p = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
+                    ++n_pieces, ++opened, acc = 0;
+                    h_pw[n_pieces] = (int)(p / BB_WIN), h_pb[n_pieces] = b, h_ps[n_pieces] = n_slots + opened - 1;
+                }
                 h_c2q[id] = (unsigned int)(p / 4);
                 p += h_cnt[id];
+                acc += h_cnt[id];
             }
+            max_piece = acc > max_piece ? acc : max_piece;
+            if (want > 1) {
+                h_jn[3 * n_join + 2] = opened;
+                n_slots += opened;
+                ++n_join;
+            }
+            ++n_pieces;
             p = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
             if (p > ((int64_t)1 << 31) - 4 * BB_WIN) {
                 rc = -2;
                 goto out;
             }
         }
-        h_bw[B] = (int)(p / BB_WIN);
+        h_pw[n_pieces] = (int)(p / BB_WIN);
         n2 = p;
-    }
-    /*
-     * An automatic choice is taken back when the plan cannot pay off (spmv_plan_choose nominates by shape alone):
-     *  - the columns are LOCAL to the rows (banded): the CSR kernels' gathers of x hit in cache and nothing is gained for the
-     *    products' extra trip through memory.  Seen from here: far fewer cells hold entries than scattered columns
-     *    would fill (a cell of mean m entries is empty with probability exp(-m));
-     *  - one bin holds half as much again as the mean (dense rows): phase 2 lasts as long as its heaviest bin's wave.
-     */
-    if (auto_choice) {
-        size_t nonempty = 0;
-        int64_t max_bin = 0;
-        for (int b = 0; b < B; ++b) {
-            int64_t e = 0;
-            for (int s = 0; s < S; ++s) {
-                const int c = h_cnt[(size_t)s * B + b];
-                nonempty += c != 0;
-                e += c;
+        /*
+         * An automatic choice is taken back when the plan cannot pay off (spmv_plan_choose nominates by shape alone):
+         *  - the columns are LOCAL to the rows (banded): the CSR kernels' gathers of x hit in cache and nothing is gained for
+         *    the products' extra trip through memory.  Seen from here: far fewer cells hold entries than scattered columns
+         *    would fill (a cell of mean m entries is empty with probability exp(-m));
+         *  - a piece that cannot be cut -- one cell -- is several times the share: phase 2 lasts as long as its heaviest
+         *    piece's wave, and a cell that crowded holds runs of one row's products, which the LDS adds one after the
+         *    other (R-MAT 2^21: a cell of 106 000 entries where the mean BIN has 16 000, 62 % of all entries follow one of
+         *    their own row; BLOCKED by name 2.8 ms, STREAM 0.26).
+         */
+        if (auto_choice) {
+            size_t nonempty = 0;
+            for (size_t id = 0; id < ncells; ++id)
+                nonempty += h_cnt[id] != 0;
+            const double mean_cell = (double)nnz / (double)ncells;
+            const double expected = (double)ncells * (1.0 - exp(-mean_cell));
+            if ((double)nonempty < 0.6 * expected || max_piece > 3 * share) {
+                rc = -2;
+                goto out;
             }
-            max_bin = e > max_bin ? e : max_bin;
-        }
-        const double mean_cell = (double)nnz / (double)ncells;
-        const double expected = (double)ncells * (1.0 - exp(-mean_cell));
-        if ((double)nonempty < 0.6 * expected || (double)max_bin > 1.5 * (double)n2 / (double)B + 2048.0) {
-            rc = -2;
-            goto out;
         }
     }
     /* ---- phase 1's workgroups: one per stripe; a stripe with more than 5/4 of the mean share is cut */
@@ -505,11 +572,19 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     BKCHK(hipMalloc(&d.prod, ((size_t)n2 + 4) * (size_t)elem_size)); /* + the spare group */
     BKCHK(hipMalloc((void **)&d.lrow, (size_t)n2 * sizeof(unsigned short)));
     BKCHK(hipMalloc((void **)&d.wg, ((size_t)n_wg + 1) * 3 * sizeof(int)));
-    BKCHK(hipMalloc((void **)&d.bw, ((size_t)B + 1) * sizeof(int)));
+    BKCHK(hipMalloc((void **)&d.pw, ((size_t)n_pieces + 1) * sizeof(int)));
+    BKCHK(hipMalloc((void **)&d.pb, ((size_t)n_pieces + 1) * sizeof(int)));
+    BKCHK(hipMalloc((void **)&d.ps, ((size_t)n_pieces + 1) * sizeof(int)));
+    BKCHK(hipMalloc((void **)&d.jn, ((size_t)n_join + 1) * 3 * sizeof(int)));
+    BKCHK(hipMalloc((void **)&d.part, ((size_t)n_slots * RB + 1) * sizeof(double)));
     BKCHK(hipMemcpyAsync(d_c1q, h_c1q, (ncells + 1) * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     BKCHK(hipMemcpyAsync(d_c2q, h_c2q, ncells * sizeof(unsigned int), hipMemcpyHostToDevice, st));
     BKCHK(hipMemcpyAsync(d.wg, h_wg, (size_t)n_wg * 3 * sizeof(int), hipMemcpyHostToDevice, st));
-    BKCHK(hipMemcpyAsync(d.bw, h_bw, ((size_t)B + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    BKCHK(hipMemcpyAsync(d.pw, h_pw, ((size_t)n_pieces + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    BKCHK(hipMemcpyAsync(d.pb, h_pb, (size_t)n_pieces * sizeof(int), hipMemcpyHostToDevice, st));
+    BKCHK(hipMemcpyAsync(d.ps, h_ps, (size_t)n_pieces * sizeof(int), hipMemcpyHostToDevice, st));
+    if (n_join)
+        BKCHK(hipMemcpyAsync(d.jn, h_jn, (size_t)n_join * 3 * sizeof(int), hipMemcpyHostToDevice, st));
     BKCHK(hipMemsetAsync(d.val1, 0, (size_t)n1 * (size_t)elem_size, st));
     BKCHK(hipMemsetAsync(d.prod, 0, ((size_t)n2 + 4) * (size_t)elem_size, st));
     BKCHK(hipMemsetAsync(d.lrow, 0, (size_t)n2 * sizeof(unsigned short), st));
@@ -529,13 +604,14 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     BKCHK(hipGetLastError());
     BKCHK(hipStreamSynchronize(st));
     d.elem = elem_size, d.rows = rows, d.cols = cols, d.nnz = nnz, d.S = S, d.wcols = wcols, d.W = W, d.RB = RB, d.B = B;
-    d.n_wg = n_wg, d.n1 = n1, d.n2 = n2;
-    d.bytes = (size_t)n1 * ((size_t)elem_size + 3) + (size_t)n2 * ((size_t)elem_size + 2) + ((size_t)n_wg + 1) * 12 + ((size_t)B + 1) * 4;
+    d.n_wg = n_wg, d.n1 = n1, d.n2 = n2, d.n_pieces = n_pieces, d.n_slots = n_slots, d.n_join = n_join;
+    d.bytes = (size_t)n1 * ((size_t)elem_size + 3) + (size_t)n2 * ((size_t)elem_size + 2) + ((size_t)n_wg + 1) * 12 + ((size_t)n_pieces + 1) * 12 +
+              ((size_t)n_join + 1) * 12 + ((size_t)n_slots * RB + 1) * 8;
     *out = d;
     memset(&d, 0, sizeof d);
 out:
     (void)hipFree(d_cnt), (void)hipFree(d_c1q), (void)hipFree(d_c2q);
-    free(h_cnt), free(h_c1q), free(h_c2q), free(stripe_w0), free(h_bw), free(h_wg);
+    free(h_cnt), free(h_c1q), free(h_c2q), free(stripe_w0), free(h_wg), free(h_pw), free(h_pb), free(h_ps), free(h_jn), free(bin_e);
     if (rc != 0) {
         (void)hipGetLastError();
         spmv_blocked_free(&d);
@@ -550,10 +626,11 @@ template <typename T> static void launch_blocked(const spmv_dev_blocked *d, cons
 {
     hipLaunchKernelGGL((k_blk_products<T, 2>), dim3(d->n_wg), dim3(BB_P1_WAVES * 64), 0, st, d->wg, (const T *)d->val1, d->col1,
                        d->dest4, (const T *)x, d->cols, d->wcols, (T *)d->prod);
-    const dim3 g2((d->B + 3) / 4);
+    const dim3 g2((d->n_pieces + 3) / 4);
 #define BLK_BINS(RB_)                                                                                                          \
     case RB_:                                                                                                                  \
-        hipLaunchKernelGGL((k_blk_bins<T, 2, RB_>), g2, dim3(256), 0, st, d->bw, (const T *)d->prod, d->lrow, d->rows, d->B, (T *)y); \
+        hipLaunchKernelGGL((k_blk_bins<T, 2, RB_>), g2, dim3(256), 0, st, d->pw, d->pb, d->ps, (const T *)d->prod, d->lrow, d->rows, \
+                           d->n_pieces, (T *)y, d->part);                                                                   \
         break
     switch (d->RB) {
         BLK_BINS(1024);
@@ -565,6 +642,8 @@ template <typename T> static void launch_blocked(const spmv_dev_blocked *d, cons
         BLK_BINS(2560);
     }
 #undef BLK_BINS
+    if (d->n_join)
+        hipLaunchKernelGGL(k_blk_join<T>, dim3(d->n_join), dim3(256), 0, st, d->jn, d->part, d->RB, d->rows, (T *)y);
 }
 
 extern "C" int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *stream)

@@ -1005,7 +1005,7 @@ static int n_launches(const spmv_hip_matrix *m)
     int longk = m->sp.nseg > 0 ? 1 + (m->sp.nlrow > 0) : 0;
     switch (m->plan) {
     case SPMV_HIP_PLAN_STRIPED: return m->ds.NG > 1 ? 2 : 1;
-    case SPMV_HIP_PLAN_BLOCKED: return 2;
+    case SPMV_HIP_PLAN_BLOCKED: return m->db.n_join > 0 ? 3 : 2; /* + k_blk_join when a bin was cut */
     case SPMV_HIP_PLAN_STREAM: return 1 + longk;
     case SPMV_HIP_PLAN_BINNED: {
         int n = longk;

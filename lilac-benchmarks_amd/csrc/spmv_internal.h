@@ -230,8 +230,10 @@ typedef struct spmv_dev_blocked {
     int *wg;           /* [n_wg * 3] phase-1 workgroups: stripe, first window, end window                          */
     void *prod;        /* T[n2] the products in phase-2 order (bin, stripe, row): scratch, rewritten by every call */
     uint16_t *lrow;    /* [n2] bin-local row of every product                                                      */
-    int *bw;           /* [B + 1] first window of every bin in the phase-2 stream                                  */
-    int elem, rows, cols, S, wcols, W, RB, B, n_wg;
+    int *pw, *pb, *ps; /* phase 2's pieces: [n_pieces + 1] first window, [n_pieces] bin, [n_pieces] slot of its partial sums or -1 */
+    int *jn;           /* [n_join * 3] cut bins: bin, first slot, slots                                             */
+    double *part;      /* [n_slots * RB] partial sums of the pieces of cut bins: scratch                           */
+    int elem, rows, cols, S, wcols, W, RB, B, n_wg, n_pieces, n_slots, n_join;
     int64_t nnz, n1, n2;
     size_t bytes;
 } spmv_dev_blocked;

@@ -383,7 +383,7 @@ void spmv_plan_choose(const spmv_row_stats *st, int elem_size, int cols, int *pl
      * plan is cheaper still (17 instead of 30 bytes per entry through memory) but so are the gathers (16 elements per line):
      * 120^3 44 / 70, 100^3 32 / 30: from 1.25 M columns (5 MB) on, against 0.94 M columns (7.5 MB) of doubles.
      */
-    if (cols >= (elem_size == 8 ? 983040 : 1310720) && st->nnz >= 4000000 && st->rows >= 262144 && st->max_len <= 65536) {
+    if (cols >= (elem_size == 8 ? 983040 : 1310720) && st->nnz >= 4000000 && st->rows >= 262144 && st->max_len <= 1048576) {
         *plan = SPMV_HIP_PLAN_BLOCKED;
         *param = 0;
         return;

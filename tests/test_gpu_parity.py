@@ -1315,7 +1315,7 @@ def test_blocked_plan(pkg, backend, oracle):
             try:
                 m.set_plan(pkg.PLAN_BLOCKED, 0)
                 inf = m.info()
-                assert inf["plan"] == pkg.PLAN_BLOCKED and inf["n_launches"] == 2
+                assert inf["plan"] == pkg.PLAN_BLOCKED and inf["n_launches"] == 2, (name, inf)  # one bin, or even bins: none is cut
                 y = m.spmv_host(x)
                 assert_close_rows(y, y_ref, absum, np.diff(rs), dtype, name, CSR)
                 for _ in range(3):
@@ -1407,7 +1407,7 @@ def test_auto_takes_blocked_for_scattered_columns_only(pkg, backend, oracle):
                           np.float64, "banded, BLOCKED by name", CSR)
     finally:
         m.close()
-    # scattered columns, one row with 600 000 entries more: its bin would run long after the others
+    # scattered columns, one row with 600 000 entries more: its bin is cut into pieces whose partial sums a third launch adds
     r0, extra = rows // 3, 600_000
     p = int(rs[r0 + 1]) - 1
     ci2 = np.concatenate([ci[:p], rng.integers(1, rows + 1, extra).astype(np.int32), ci[p:]])
@@ -1416,9 +1416,12 @@ def test_auto_takes_blocked_for_scattered_columns_only(pkg, backend, oracle):
     rs2[r0 + 1:] += extra
     m = backend.matrix(a2, rs2, ci2, rows)
     try:
-        assert m.info()["plan"] != pkg.PLAN_BLOCKED, m.info()
-        assert_close_rows(m.spmv_host(x), oracle.spmv(a2, x, rs2, ci2, rows), oracle.absum(a2, x, rs2, ci2, rows), np.diff(rs2),
+        inf = m.info()
+        assert inf["plan"] == pkg.PLAN_BLOCKED and inf["n_launches"] == 3, inf
+        y = m.spmv_host(x)
+        assert_close_rows(y, oracle.spmv(a2, x, rs2, ci2, rows), oracle.absum(a2, x, rs2, ci2, rows), np.diff(rs2),
                           np.float64, "one heavy row", CSR)
+        assert np.array_equal(bits(m.spmv_host(x)), bits(y))
     finally:
         m.close()
 

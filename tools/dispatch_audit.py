@@ -82,7 +82,7 @@ def main():
     for rows, scale in ((40000, 30.0), (300000, 8.0)):
         lens = np.minimum((rng.pareto(1.3, rows) * scale).astype(np.int64), rows // 2)
         extra.append(("pareto %d" % rows,) + matgen.csr_from_lengths(rng, [int(v) for v in lens], rows, dtype))
-    for sc in (15, 17, 19):
+    for sc in (15, 17, 19, 21):
         extra.append(("rmat%d" % sc,) + matgen.rmat_graph(20, sc, 16, dtype, values="normal"))
     # SparseBench-like: short rows, uniformly scattered columns, x from 8 to 33 MB (BLOCKED's ground from 16 MB on)
     for size in (100, 120, 128, 140, 160):
