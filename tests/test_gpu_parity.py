@@ -1293,6 +1293,7 @@ def test_blocked_plan(pkg, backend, oracle):
     """The BLOCKED plan (csrc/spmv_blocked.hip): phase 1 streams the entries stripe-major with the stripe of x in LDS and writes
     the products bin-major, phase 2 adds them, one wave per bin of rows, in LDS.  Its own shapes: several stripes and bins
     (x of 5-40 MB), short rows (SparseBench-like), long rows (one address of a bin's slice taking thousands of additions),
+    a bin that is cut into pieces (third launch),
     empty rows, a row count below one bin, rows with unsorted and repeated columns; every bin size; f64 and f32; results
     within the CSR bar, the same bits on every repetition, in a second build of the layout and after a value refresh; a
     matrix with more columns than 2048 stripes hold is refused."""
@@ -1305,6 +1306,7 @@ def test_blocked_plan(pkg, backend, oracle):
             "few_rows": matgen.random_csr(101, 37, 1_000_000, 300, dtype, spread=0.2),
             "one_long_row": matgen.csr_from_lengths(rng, [3] * 100 + [200000] + [2] * 200, 700_000, dtype),
             "unsorted_rows": matgen.random_csr(102, 30000, 3_000_000, 12, dtype, sort_cols=False, distinct=False),
+            "heavy_bin": matgen.csr_from_lengths(rng, [5] * 3000 + [100000] + [5] * 3000, 2_000_000, dtype),  # 6 bins, one is cut
         }
         for name, (rs, ci, a) in cases.items():
             rows = rs.size - 1
@@ -1315,7 +1317,7 @@ def test_blocked_plan(pkg, backend, oracle):
             try:
                 m.set_plan(pkg.PLAN_BLOCKED, 0)
                 inf = m.info()
-                assert inf["plan"] == pkg.PLAN_BLOCKED and inf["n_launches"] == 2, (name, inf)  # one bin, or even bins: none is cut
+                assert inf["plan"] == pkg.PLAN_BLOCKED and inf["n_launches"] == (3 if name == "heavy_bin" else 2), (name, inf)
                 y = m.spmv_host(x)
                 assert_close_rows(y, y_ref, absum, np.diff(rs), dtype, name, CSR)
                 for _ in range(3):
