@@ -26,7 +26,7 @@ for size in sizes:
     auto = pkg.abi.PLAN_NAMES[inf["plan"]]
     dm.close()
     line = "sb%d rows=%d nnz=%d x=%.1f MB auto=%s stream %.1f us;" % (size, sb.rows, inf["nnz"], inf["cols"] * 8 / 1e6, auto, t_stream)
-    for bin_rows in (0,):
+    for bin_rows in [int(v[6:]) for v in sys.argv[1:] if v.startswith("--bins")] or (0,):
         be.set_tuning(18, bin_rows)
         dm = be.matrix(a, rs, ci, sb.rows)
         import time
