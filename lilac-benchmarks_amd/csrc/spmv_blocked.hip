@@ -35,6 +35,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -331,15 +332,16 @@ __global__ void __launch_bounds__(256) k_bb_fill16(unsigned short *__restrict__ 
         p[i] = (unsigned short)v;
 }
 
-int g_blk_bin_rows = 0; /* rows per bin of phase 2 (tuning key 18: 0 = by the row count, or one of the instantiated sizes), read when a layout is built */
+std::atomic<int> g_blk_bin_rows{0}; /* rows per bin of phase 2 (tuning key 18: 0 = by the row count, or one of the instantiated sizes), read when a layout is built */
 
 /* Rows per bin.  Phase 2 runs one wave per bin, four waves and 4 RB sizeof(T) bytes of LDS per workgroup: up to 2560 rows
  * two workgroups share a CU -- 2048 waves at a time on 256 CUs.  A matrix with a few more bins than that pays a second,
  * nearly empty round (SparseBench 170^3 in bins of 2048 rows: 2399 bins), so the bins are sized to fill whole rounds. */
 int choose_bin_rows(int rows)
 {
-    if (g_blk_bin_rows)
-        return g_blk_bin_rows;
+    const int forced = g_blk_bin_rows.load(std::memory_order_relaxed);
+    if (forced)
+        return forced;
     const int64_t slots = 2048, rb_max = 2560;
     const int64_t rounds = (rows + slots * rb_max - 1) / (slots * rb_max);
     int64_t rb = (rows + slots * rounds - 1) / (slots * rounds);
@@ -357,10 +359,10 @@ extern "C" void spmv_blocked_free(spmv_dev_blocked *d)
     memset(d, 0, sizeof *d);
 }
 
-extern "C" void spmvk_blocked_set_wgs(int bin_rows)
+extern "C" void spmvk_blocked_set_bin_rows(int bin_rows)
 {
     if (bin_rows == 0 || (bin_rows >= 1024 && bin_rows <= 2560 && bin_rows % 256 == 0))
-        g_blk_bin_rows = bin_rows;
+        g_blk_bin_rows.store(bin_rows, std::memory_order_relaxed);
 }
 
 /*

@@ -31,7 +31,7 @@
 #include "spmv_internal.h"
 
 extern "C" void spmvk_set_tuning(int key, int value);
-extern "C" void spmvk_blocked_set_wgs(int per_xcd);
+extern "C" void spmvk_blocked_set_bin_rows(int per_xcd);
 extern "C" int spmvk_get_tuning_xcd(void);
 static bool g_tune_xcd_enabled() { return spmvk_get_tuning_xcd() != 0; }
 
@@ -1417,7 +1417,7 @@ void spmv_hip_set_tuning(int key, int value)
     else if (key == 19 && value >= -200 && value <= 200)
         g_stripe_xcd_bias = value; /* STRIPED: per mille of weight moved from even-XCD workgroups to odd-XCD ones */
     else if (key == 18)
-        spmvk_blocked_set_wgs(value); /* BLOCKED: rows per bin of layouts built from now on */
+        spmvk_blocked_set_bin_rows(value); /* BLOCKED: rows per bin of layouts built from now on */
     else if (key == 17 && value >= 0 && value <= 2)
         g_striped_builder = value; /* 0: the device builds the STRIPED layout (the host when it must), 1: host, 2: device or fail */
     else if (key == 15 && value >= 0 && value <= 2)
