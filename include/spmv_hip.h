@@ -79,6 +79,7 @@ typedef struct spmv_hip_stats {
 
 /* ---- runtime ------------------------------------------------------------- */
 int spmv_hip_device_count(void);            /* visible GPUs; 0 when there is none (no abort)  */
+int64_t spmv_hip_device_free_bytes(int device); /* free device memory right now (hipMemGetInfo); -1 on error */
 const char *spmv_hip_version(void);
 const char *spmv_hip_last_error(void);      /* message of the last failed int-returning call  */
 

@@ -60,6 +60,8 @@ class Backend:
             fn.restype = ctypes.c_void_p
             fn.argtypes = [ctypes.c_void_p] * 6
         L.spmv_hip_device_count.restype = ctypes.c_int
+        L.spmv_hip_device_free_bytes.restype = ctypes.c_int64
+        L.spmv_hip_device_free_bytes.argtypes = [ctypes.c_int]
         L.spmv_hip_version.restype = ctypes.c_char_p
         L.spmv_hip_last_error.restype = ctypes.c_char_p
         L.spmv_hip_matrix_create.restype = ctypes.c_void_p
@@ -135,6 +137,9 @@ class Backend:
     # ---- extended API -------------------------------------------------------------------
     def device_count(self):
         return int(self.lib.spmv_hip_device_count())
+
+    def device_free_bytes(self, device=0):
+        return int(self.lib.spmv_hip_device_free_bytes(device))
 
     def version(self):
         return self.lib.spmv_hip_version().decode()

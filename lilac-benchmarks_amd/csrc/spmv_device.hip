@@ -159,6 +159,19 @@ int spmv_hip_device_count(void)
     return n;
 }
 
+/* bytes of device memory free on `device` right now (hipMemGetInfo), -1 on error */
+int64_t spmv_hip_device_free_bytes(int device)
+{
+    size_t free_b = 0, total_b = 0;
+    if (use_device(device))
+        return -1;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return (int64_t)free_b;
+}
+
 /* ---- memory helpers ------------------------------------------------------------- */
 void *spmv_hip_malloc(int device, size_t bytes)
 {

@@ -1428,6 +1428,34 @@ def test_auto_takes_blocked_for_scattered_columns_only(pkg, backend, oracle):
         m.close()
 
 
+def test_relayouts_give_their_memory_back(pkg, backend):
+    """Every re-laid-out plan allocates a second copy (and scratch) on the device; creating, refreshing and closing such
+    matrices over and over must leave the device's free memory where it was (hipMemGetInfo)."""
+    rs, ci, a = matgen.npb_like(150, 60000, 150)
+    sb = pkg.callers.sb_generate(80)
+    rs2, ci2, a2 = (np.array(v) for v in sb.arrays())
+    pkg.callers.free(sb)
+    x = np.random.default_rng(150).standard_normal(max(int(ci.max()), int(ci2.max())))
+
+    def cycle():
+        for plan, (r_, c_, a_) in ((pkg.PLAN_STRIPED, (rs, ci, a)), (pkg.PLAN_TILED, (rs, ci, a)), (pkg.PLAN_BLOCKED, (rs2, ci2, a2)),
+                                   (pkg.PLAN_BLOCKED, (rs, ci, a))):
+            m = backend.matrix(a_, r_, c_, r_.size - 1)
+            m.set_plan(plan, 0)
+            m.spmv_host(x[: int(c_.max())])
+            m.refresh_values(a_ * 2.0, c_)
+            m.spmv_host(x[: int(c_.max())])
+            m.close()
+    cycle()  # the first cycle settles what the runtime keeps for itself (code objects, staging buffers)
+    backend.synchronize(0)
+    free0 = backend.device_free_bytes(0)
+    for _ in range(4):
+        cycle()
+    backend.synchronize(0)
+    free1 = backend.device_free_bytes(0)
+    assert free0 - free1 < (32 << 20), "device memory not returned: %d MB" % ((free0 - free1) >> 20)
+
+
 def test_no_room_for_the_second_copy_is_not_fatal(pkg):
     """The re-laid-out copy of a matrix (STRIPED, TILED) is an optimisation next to the CSR copy: when the device has
     no memory for it, an automatic choice falls back to the CSR kernels and the product is still right; only asking
