@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(BB_P1_WAVES * 64) k_blk_products(const int *__
 #pragma unroll
                     for (int e = 0; e < E; ++e)
                         o[e] = p[j * E + e];
-                    reinterpret_cast<VT *>(out)[j] = o;
+                    reinterpret_cast<VT *>(out)[j] = o; /* through the caches: the halves of a line meet in L2 and phase 2 finds the
+                                                           products there or in the Infinity Cache (non-temporal: 141 -> 180 us) */
                 }
             }
         }
