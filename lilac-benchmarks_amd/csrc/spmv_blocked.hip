@@ -45,8 +45,8 @@
 
 namespace {
 
-#define BB_WIN 256           /* entries per window: 64 lanes x 4 */
-#define BB_MAX_STRIPES 2048  /* per-wave cursors of the builder in LDS */
+#define BB_WIN SPMV_BLOCKED_WIN
+#define BB_MAX_STRIPES SPMV_BLOCKED_MAX_STRIPES
 #define BB_P1_WAVES 16
 
 #define BKCHK(expr)                                                                                  \
@@ -335,21 +335,6 @@ __global__ void __launch_bounds__(256) k_bb_fill16(unsigned short *__restrict__ 
 
 std::atomic<int> g_blk_bin_rows{0}; /* rows per bin of phase 2 (tuning key 18: 0 = by the row count, or one of the instantiated sizes), read when a layout is built */
 
-/* Rows per bin.  Phase 2 runs one wave per bin, four waves and 4 RB sizeof(T) bytes of LDS per workgroup: up to 2560 rows
- * two workgroups share a CU -- 2048 waves at a time on 256 CUs.  A matrix with a few more bins than that pays a second,
- * nearly empty round (SparseBench 170^3 in bins of 2048 rows: 2399 bins), so the bins are sized to fill whole rounds. */
-int choose_bin_rows(int rows)
-{
-    const int forced = g_blk_bin_rows.load(std::memory_order_relaxed);
-    if (forced)
-        return forced;
-    const int64_t slots = 2048, rb_max = 2560;
-    const int64_t rounds = (rows + slots * rb_max - 1) / (slots * rb_max);
-    int64_t rb = (rows + slots * rounds - 1) / (slots * rounds);
-    rb = (rb + 255) / 256 * 256;
-    return (int)(rb < 1024 ? 1024 : rb > rb_max ? rb_max : rb);
-}
-
 } // namespace
 
 extern "C" void spmv_blocked_free(spmv_dev_blocked *d)
@@ -379,45 +364,17 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     memset(out, 0, sizeof *out);
     if (rows <= 0 || cols <= 0 || nnz <= 0 || nnz > 0x7ffffff0ll)
         return -2;
-    /* ---- geometry: as few stripes as the LDS allows, in multiples of 256 (one per CU and round); narrow matrices get
-     * stripes of at least 64 columns */
-    const int E = 16 / elem_size;
-    const int W = elem_size == 8 ? BlkGeom<double>::W : BlkGeom<float>::W;
-    int S, wcols;
-    if (cols <= 256 * 64) {
-        wcols = 64;
-        S = (cols + wcols - 1) / wcols;
-    } else {
-        int k = 1;
-        while ((int64_t)256 * k * (W - E) < cols)
-            ++k;
-        S = 256 * k;
-        wcols = (cols + S - 1) / S;
-        wcols = (wcols + E - 1) / E * E;
-        S = (cols + wcols - 1) / wcols;
-    }
-    const int RB = choose_bin_rows(rows);
-    const int B = (rows + RB - 1) / RB;
-    const size_t ncells = (size_t)S * (size_t)B;
-    if (S > BB_MAX_STRIPES || ncells > ((size_t)1 << 24))
+    spmv_blocked_plan g;
+    if (spmv_blocked_geometry(rows, cols, elem_size, g_blk_bin_rows.load(std::memory_order_relaxed), &g))
         return -2;
-
-    int *d_cnt = nullptr, *h_cnt = nullptr, *h_wg = nullptr, *h_pw = nullptr, *h_pb = nullptr, *h_ps = nullptr, *h_jn = nullptr;
-    int64_t *bin_e = nullptr;
-    int n_pieces = 0, n_slots = 0, n_join = 0;
-    unsigned int *d_c1q = nullptr, *d_c2q = nullptr, *h_c1q = nullptr, *h_c2q = nullptr;
-    int64_t *stripe_w0 = nullptr;
-    int64_t n1 = 0, n2 = 0;
-    int n_wg = 0;
+    const int S = g.S, wcols = g.wcols, W = g.W, RB = g.RB, B = g.B;
+    const size_t ncells = (size_t)S * (size_t)B;
+    int *d_cnt = nullptr, *h_cnt = nullptr;
+    unsigned int *d_c1q = nullptr, *d_c2q = nullptr;
     spmv_dev_blocked d;
     memset(&d, 0, sizeof d);
-
     h_cnt = (int *)malloc(ncells * sizeof(int));
-    h_c1q = (unsigned int *)malloc((ncells + 1) * sizeof(unsigned int));
-    h_c2q = (unsigned int *)malloc(ncells * sizeof(unsigned int));
-    stripe_w0 = (int64_t *)malloc(((size_t)S + 1) * sizeof(int64_t));
-    bin_e = (int64_t *)calloc((size_t)B, sizeof(int64_t));
-    if (!h_cnt || !h_c1q || !h_c2q || !stripe_w0 || !bin_e) {
+    if (!h_cnt) {
         rc = -3;
         goto out;
     }
@@ -429,143 +386,17 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     BKCHK(hipGetLastError());
     BKCHK(hipMemcpyAsync(h_cnt, d_cnt, ncells * sizeof(int), hipMemcpyDeviceToHost, st));
     BKCHK(hipStreamSynchronize(st));
-    /* ---- the two orders.  Phase 1: stripe-major, cells padded to fours, a stripe to the window; phase 2:
-     * bin-major with the same padded cells, a bin's end padded to the window (slots nobody writes: they stay zero) */
+    /* ---- the decisions (spmv_blocked_plan.c): where every cell lies in both streams, workgroups, pieces, cut bins */
+    rc = spmv_blocked_plan_build(h_cnt, nnz, auto_choice, &g);
+    if (rc == -1)
+        spmv_set_error("BLOCKED builder: the entries counted per cell do not add up to the %lld of the matrix", (long long)nnz);
+    if (rc)
+        goto out;
     {
-        int64_t p = 0, total = 0;
-        for (int s = 0; s < S; ++s) {
-            stripe_w0[s] = p / BB_WIN;
-            for (int b = 0; b < B; ++b) {
-                const size_t id = (size_t)s * B + b;
-                total += h_cnt[id];
-                h_cnt[id] = (h_cnt[id] + 3) & ~3; /* from here on: the padded size (to eights: SparseBench 170^3 146 us against 144) */
-                h_c1q[id] = (unsigned int)(p / 4);
-                p += h_cnt[id];
-            }
-            /* the stripe ends on a window boundary: the groups of four behind its last cell are pads whose products (0 x 0)
-             * go to the spare group behind phase 2's stream (k_bb_dest), not into a bin */
-            p = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
-            if (p > ((int64_t)1 << 31) - 4 * BB_WIN) {
-                rc = -2;
-                goto out;
-            }
-        }
-        stripe_w0[S] = p / BB_WIN;
-        h_c1q[ncells] = (unsigned int)(p / 4);
-        n1 = p;
-        if (total != nnz) {
-            spmv_set_error("BLOCKED builder: %lld entries counted, %lld expected", (long long)total, (long long)nnz);
-            rc = -1;
-            goto out;
-        }
-        /*
-         * Phase 2's pieces.  A bin is one piece -- one wave -- unless it holds more than its share (dense rows: an R-MAT
-         * graph piles its hubs into the first bins): then it is cut, between stripes, into pieces of about the mean bin,
-         * each padded to the window; their partial sums meet in k_blk_join.
-         */
-        int64_t padded_total = 0;
-        for (int s2 = 0; s2 < S; ++s2)
-            for (int b = 0; b < B; ++b) {
-                bin_e[b] += h_cnt[(size_t)s2 * B + b];
-                padded_total += h_cnt[(size_t)s2 * B + b];
-            }
-        /* the share: a quarter above the mean bin.  More pieces than wave slots are no harm -- workgroups are handed out in
-         * order, the cut (heavy) bins' pieces among the first, and a light bin's wave is gone in no time */
-        const int64_t share = (padded_total / B + 1) * 5 / 4 + 1024;
-        size_t cap_pieces = 0;
-        for (int b = 0; b < B; ++b)
-            cap_pieces += (size_t)(bin_e[b] > share * 6 / 5 ? (bin_e[b] + share - 1) / share : 1);
-        h_pw = (int *)malloc((cap_pieces + 1) * sizeof(int));
-        h_pb = (int *)malloc((cap_pieces + 1) * sizeof(int));
-        h_ps = (int *)malloc((cap_pieces + 1) * sizeof(int));
-        h_jn = (int *)malloc(((size_t)B + 1) * 3 * sizeof(int));
-        if (!h_pw || !h_pb || !h_ps || !h_jn) {
-            rc = -3;
-            goto out;
-        }
-        p = 0;
-        int64_t max_piece = 0;
-        for (int b = 0; b < B; ++b) {
-            const int want = (int)(bin_e[b] > share * 6 / 5 ? (bin_e[b] + share - 1) / share : 1);
-            const int64_t per = (bin_e[b] + want - 1) / want;
-            int opened = 1;
-            int64_t acc = 0;
-            h_pw[n_pieces] = (int)(p / BB_WIN), h_pb[n_pieces] = b, h_ps[n_pieces] = want > 1 ? n_slots : -1;
-            if (want > 1)
-                h_jn[3 * n_join] = b, h_jn[3 * n_join + 1] = n_slots;
-            for (int s2 = 0; s2 < S; ++s2) {
-                const size_t id = (size_t)s2 * B + b;
-                if (acc >= per && opened < want && h_cnt[id]) { /* the next piece of this bin starts with this stripe */
-                    max_piece = acc > max_piece ? acc : max_piece;
-                    p = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
-                    ++n_pieces, ++opened, acc = 0;
-                    h_pw[n_pieces] = (int)(p / BB_WIN), h_pb[n_pieces] = b, h_ps[n_pieces] = n_slots + opened - 1;
-                }
-                h_c2q[id] = (unsigned int)(p / 4);
-                p += h_cnt[id];
-                acc += h_cnt[id];
-            }
-            max_piece = acc > max_piece ? acc : max_piece;
-            if (want > 1) {
-                h_jn[3 * n_join + 2] = opened;
-                n_slots += opened;
-                ++n_join;
-            }
-            ++n_pieces;
-            p = (p + BB_WIN - 1) / BB_WIN * BB_WIN;
-            if (p > ((int64_t)1 << 31) - 4 * BB_WIN) {
-                rc = -2;
-                goto out;
-            }
-        }
-        h_pw[n_pieces] = (int)(p / BB_WIN);
-        n2 = p;
-        /*
-         * An automatic choice is taken back when the plan cannot pay off (spmv_plan_choose nominates by shape alone):
-         *  - the columns are LOCAL to the rows (banded): the CSR kernels' gathers of x hit in cache and nothing is gained for
-         *    the products' extra trip through memory.  Seen from here: far fewer cells hold entries than scattered columns
-         *    would fill (a cell of mean m entries is empty with probability exp(-m));
-         *  - a piece that cannot be cut -- one cell -- is several times the share: phase 2 lasts as long as its heaviest
-         *    piece's wave, and a cell that crowded holds runs of one row's products, which the LDS adds one after the
-         *    other (R-MAT 2^21: a cell of 106 000 entries where the mean BIN has 16 000, 62 % of all entries follow one of
-         *    their own row; BLOCKED by name 2.8 ms, STREAM 0.26).
-         */
-        if (auto_choice) {
-            size_t nonempty = 0;
-            for (size_t id = 0; id < ncells; ++id)
-                nonempty += h_cnt[id] != 0;
-            const double mean_cell = (double)nnz / (double)ncells;
-            const double expected = (double)ncells * (1.0 - exp(-mean_cell));
-            if ((double)nonempty < 0.6 * expected || max_piece > 3 * share) {
-                rc = -2;
-                goto out;
-            }
-        }
-    }
-    /* ---- phase 1's workgroups: one per stripe; a stripe with more than 5/4 of the mean share is cut */
-    {
-        const int64_t slots = S > 256 ? S : 256;
-        int64_t target = (stripe_w0[S] + slots - 1) / slots;
-        target = target * 5 / 4 > 0 ? target * 5 / 4 : 1;
-        size_t cap = 0;
-        for (int s = 0; s < S; ++s)
-            cap += (size_t)((stripe_w0[s + 1] - stripe_w0[s] + target - 1) / target);
-        h_wg = (int *)malloc((cap + 1) * 3 * sizeof(int));
-        if (!h_wg) {
-            rc = -3;
-            goto out;
-        }
-        for (int s = 0; s < S; ++s) {
-            const int64_t a = stripe_w0[s], e = stripe_w0[s + 1];
-            const int parts = (int)((e - a + target - 1) / target);
-            for (int q = 0; q < parts; ++q) {
-                h_wg[3 * n_wg] = s;
-                h_wg[3 * n_wg + 1] = (int)(a + (e - a) * q / parts);
-                h_wg[3 * n_wg + 2] = (int)(a + (e - a) * (q + 1) / parts);
-                ++n_wg;
-            }
-        }
-    }
+    const int64_t n1 = g.n1, n2 = g.n2;
+    const int n_wg = g.n_wg, n_pieces = g.n_pieces, n_slots = g.n_slots, n_join = g.n_join;
+    const unsigned int *h_c1q = g.c1q, *h_c2q = g.c2q;
+    const int *h_wg = g.wg, *h_pw = g.pw, *h_pb = g.pb, *h_ps = g.ps, *h_jn = g.jn;
     /* ---- pass 2: the entries to their places */
     BKCHK(hipMalloc((void **)&d_c1q, (ncells + 1) * sizeof(unsigned int)));
     BKCHK(hipMalloc((void **)&d_c2q, ncells * sizeof(unsigned int)));
@@ -612,9 +443,11 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
               ((size_t)n_join + 1) * 12 + ((size_t)n_slots * RB + 1) * 8;
     *out = d;
     memset(&d, 0, sizeof d);
+    }
 out:
     (void)hipFree(d_cnt), (void)hipFree(d_c1q), (void)hipFree(d_c2q);
-    free(h_cnt), free(h_c1q), free(h_c2q), free(stripe_w0), free(h_wg), free(h_pw), free(h_pb), free(h_ps), free(h_jn), free(bin_e);
+    free(h_cnt);
+    spmv_blocked_plan_free(&g);
     if (rc != 0) {
         (void)hipGetLastError();
         spmv_blocked_free(&d);
@@ -654,6 +487,10 @@ extern "C" int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, 
     hipStream_t st = (hipStream_t)stream;
     if (d->rows <= 0)
         return 0;
+    if (d->W != (d->elem == 8 ? BlkGeom<double>::W : BlkGeom<float>::W)) { /* the layout was planned for another kernel */
+        spmv_set_error("BLOCKED: layout planned for %d elements of x in LDS", d->W);
+        return -1;
+    }
     if (d->elem == 8)
         launch_blocked<double>(d, x, y, st);
     else

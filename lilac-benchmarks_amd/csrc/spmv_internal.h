@@ -237,6 +237,23 @@ typedef struct spmv_dev_blocked {
     int64_t nnz, n1, n2;
     size_t bytes;
 } spmv_dev_blocked;
+/* the host side of the layout (spmv_blocked_plan.c): geometry and, from the entries of every cell, where the cells lie */
+#define SPMV_BLOCKED_WIN 256           /* entries per window: 64 lanes x 4 */
+#define SPMV_BLOCKED_MAX_STRIPES 2048  /* per-wave cursors of the device builder in LDS */
+#define SPMV_BLOCKED_MAX_BIN_ROWS 2560 /* two workgroups of 4 waves x RB doubles per CU */
+typedef struct spmv_blocked_plan {
+    int S, wcols, W, RB, B;               /* stripes, columns per stripe, LDS elements, rows per bin, bins */
+    int n_wg, n_pieces, n_slots, n_join;
+    int64_t n1, n2;                       /* entries of the two streams, pads included */
+    uint32_t *c1q, *c2q;                  /* [S * B + 1], [S * B]: a cell's start / 4 in the phase-1 and phase-2 streams */
+    int *wg;                              /* [n_wg * 3] */
+    int *pw, *pb, *ps;                    /* [n_pieces + 1], [n_pieces], [n_pieces] */
+    int *jn;                              /* [n_join * 3] */
+} spmv_blocked_plan;
+int spmv_blocked_lds_elems(int elem_size);
+int spmv_blocked_geometry(int rows, int cols, int elem_size, int bin_rows, spmv_blocked_plan *g);
+int spmv_blocked_plan_build(int *cnt, int64_t nnz, int auto_choice, spmv_blocked_plan *g);
+void spmv_blocked_plan_free(spmv_blocked_plan *g);
 /* auto_choice: decline (-2) a matrix the plan does not suit (columns local to the rows, one bin far heavier than the rest) */
 int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, const void *d_val, int rows, int cols, int elem_size,
                               int64_t nnz, int auto_choice, void *stream, spmv_dev_blocked *out);
