@@ -145,11 +145,59 @@ __global__ void __launch_bounds__(BB_P1_WAVES * 64) k_blk_products(const int *__
 }
 
 /* ---------------------------------------------------------------- phase 2 */
+/*
+ * N consecutive products of the stream per lane, lanes in stream order: every RUN of products of one row -- a row's entries
+ * in a cell are neighbours in the stream -- is summed first (inside the lane, then across lanes with the segmented wave scan
+ * of k_striped, started wherever the row changes) and reaches the LDS as ONE addition, by the lane where the run ends.
+ * Without this a dense row is a queue: 64 lanes adding to one address take their turns (R-MAT 2^21 by name: 530 us without,
+ * 398 with; profiles/r03_blocked_runs.log).  Runs that span two windows are two additions.  Costs 2-4 % where there are no
+ * runs (SparseBench 170^3 141-146 -> 146, 130^3 74-76 -> 78), so a layout asks for it only when some row is long enough
+ * to have two entries per stripe on average (spmv_dev_blocked.runs).
+ */
+template <int N>
+__device__ __forceinline__ void add_runs(double *__restrict__ sy, const unsigned int (&row)[N], const double (&val)[N], int lane)
+{
+    const unsigned int head_row = row[0];
+    unsigned int cur_row = row[0];
+    double cur = val[0], head_val = 0.0;
+    int nb = 0; /* row changes inside the lane */
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        if (row[i] == cur_row) {
+            cur = cur + val[i];
+        } else {
+            if (nb == 0)
+                head_val = cur; /* the lane's first run: may have begun in the lanes below */
+            else
+                unsafeAtomicAdd(&sy[cur_row], cur); /* begins and ends inside the lane */
+            ++nb;
+            cur_row = row[i];
+            cur = val[i];
+        }
+    }
+    const unsigned int prev_tail = (unsigned int)dpp_mov<0x138, 0xf>((int)cur_row); /* wave_shr:1 */
+    const int c = lane != 0 && prev_tail == head_row;                             /* my first run continues the lane below's last */
+    double sv = cur;
+    int sf = !(nb == 0 && c); /* my last run starts here (a row change inside the lane, or nothing to continue) */
+    segscan_step<double, 0x111, 0xf>(sv, sf); /* row_shr:1 */
+    segscan_step<double, 0x112, 0xf>(sv, sf); /* row_shr:2 */
+    segscan_step<double, 0x114, 0xf>(sv, sf); /* row_shr:4 */
+    segscan_step<double, 0x118, 0xf>(sv, sf); /* row_shr:8 */
+    segscan_step<double, 0x142, 0xa>(sv, sf); /* row_bcast:15 */
+    segscan_step<double, 0x143, 0xc>(sv, sf); /* row_bcast:31 */
+    const double below = dpp_mov<0x138, 0xf>(sv);  /* the lane below's last run, summed up to there */
+    const int c_next = dpp_mov<0x130, 0xf>(c);     /* wave_shl:1: does the lane above continue my last run?  (lane 63: no) */
+    if (nb != 0)
+        unsafeAtomicAdd(&sy[head_row], c ? below + head_val : head_val);
+    if (!c_next)
+        unsafeAtomicAdd(&sy[cur_row], sv);
+}
+
 /* One wave per PIECE of the phase-2 stream: windows [pw[i], pw[i+1]), all of bin pb[i] -- rows [b RB, b RB + RB) -- or, for a
  * bin that holds more than its share (dense rows), a run of its stripes; then ps[i] >= 0 names the slot of the piece's
  * partial sums and k_blk_join adds a bin's slots in order.  The stream is linear: lane l takes the products
  * j * 64 E + l E .. + E - 1 of a window with its j-th 16-byte load */
-template <typename T, int U, int RB>
+template <typename T, int U, int RB, bool RUNS>
 __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ pw, const int *__restrict__ pb,
                                                   const int *__restrict__ ps, const T *__restrict__ prod,
                                                   const unsigned short *__restrict__ lrow, int rows, int npieces,
@@ -197,10 +245,20 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ pw, co
                 load(u, k + u + U);
                 if (k + u < e) { /* wave-uniform */
 #pragma unroll
-                    for (int j = 0; j < NV; ++j)
+                    for (int j = 0; j < NV; ++j) {
+                        unsigned int rw[E];
+                        double pv[E];
 #pragma unroll
                         for (int i = 0; i < E; ++i)
-                            unsafeAtomicAdd(&s_y[w][rr[j][i]], (double)q[j][i]);
+                            rw[i] = rr[j][i], pv[i] = (double)q[j][i];
+                        if constexpr (RUNS) {
+                            add_runs<E>(s_y[w], rw, pv, lane);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < E; ++i)
+                                unsafeAtomicAdd(&s_y[w][rw[i]], pv[i]);
+                        }
+                    }
                 }
             }
         }
@@ -216,18 +274,26 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ pw, co
     }
 }
 
-/* workgroup per cut bin: jn[3 q] = bin, jn[3 q + 1] = its first slot, jn[3 q + 2] = its slots; added in slot order */
+/* workgroup (q, c): rows [256 c, 256 c + 256) of cut bin jn[3 q]; jn[3 q + 1] = its first slot, jn[3 q + 2] = its slots, added in
+ * slot order (four loads in flight: a bin of an R-MAT graph's hubs has hundreds of slots) */
 template <typename T>
 __global__ void __launch_bounds__(256) k_blk_join(const int *__restrict__ jn, const double *__restrict__ part, int rb, int rows,
                                                   T *__restrict__ y)
 {
     const int b = jn[3 * blockIdx.x], s0 = jn[3 * blockIdx.x + 1], n = jn[3 * blockIdx.x + 2];
-    for (int i = threadIdx.x; i < rb && b * rb + i < rows; i += 256) {
-        double sum = part[(size_t)s0 * rb + i];
-        for (int k = 1; k < n; ++k)
-            sum = sum + part[(size_t)(s0 + k) * rb + i];
-        y[b * rb + i] = (T)sum;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= rb || b * rb + i >= rows)
+        return;
+    const double *p = part + (size_t)s0 * rb + i;
+    double sum = p[0];
+    int k = 1;
+    for (; k + 4 <= n; k += 4) {
+        const double v0 = p[(size_t)k * rb], v1 = p[(size_t)(k + 1) * rb], v2 = p[(size_t)(k + 2) * rb], v3 = p[(size_t)(k + 3) * rb];
+        sum = (((sum + v0) + v1) + v2) + v3;
     }
+    for (; k < n; ++k)
+        sum = sum + p[(size_t)k * rb];
+    y[b * rb + i] = (T)sum;
 }
 
 /* ---------------------------------------------------------------- the builder */
@@ -465,8 +531,12 @@ template <typename T> static void launch_blocked(const spmv_dev_blocked *d, cons
     const dim3 g2((d->n_pieces + 3) / 4);
 #define BLK_BINS(RB_)                                                                                                          \
     case RB_:                                                                                                                  \
-        hipLaunchKernelGGL((k_blk_bins<T, 2, RB_>), g2, dim3(256), 0, st, d->pw, d->pb, d->ps, (const T *)d->prod, d->lrow, d->rows, \
-                           d->n_pieces, (T *)y, d->part);                                                                   \
+        if (d->runs)                                                                                                           \
+            hipLaunchKernelGGL((k_blk_bins<T, 2, RB_, true>), g2, dim3(256), 0, st, d->pw, d->pb, d->ps, (const T *)d->prod, d->lrow, \
+                               d->rows, d->n_pieces, (T *)y, d->part);                                                           \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((k_blk_bins<T, 2, RB_, false>), g2, dim3(256), 0, st, d->pw, d->pb, d->ps, (const T *)d->prod, d->lrow, \
+                               d->rows, d->n_pieces, (T *)y, d->part);                                                           \
         break
     switch (d->RB) {
         BLK_BINS(1024);
@@ -479,7 +549,8 @@ template <typename T> static void launch_blocked(const spmv_dev_blocked *d, cons
     }
 #undef BLK_BINS
     if (d->n_join)
-        hipLaunchKernelGGL(k_blk_join<T>, dim3(d->n_join), dim3(256), 0, st, d->jn, d->part, d->RB, d->rows, (T *)y);
+        hipLaunchKernelGGL(k_blk_join<T>, dim3(d->n_join, (d->RB + 255) / 256), dim3(256), 0, st, d->jn, d->part, d->RB, d->rows,
+                           (T *)y);
 }
 
 extern "C" int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *stream)

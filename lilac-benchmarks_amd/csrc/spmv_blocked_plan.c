@@ -186,7 +186,10 @@ int spmv_blocked_plan_build(int *cnt, int64_t nnz, int auto_choice, spmv_blocked
          *  - a piece that cannot be cut -- one cell -- is several times the share: phase 2 lasts as long as its heaviest
          *    piece's wave, and a cell that crowded holds runs of one row's products, which the LDS adds one after the
          *    other (R-MAT 2^21: a cell of 106 000 entries where the mean BIN has 16 000, 62 % of all entries follow one of
-         *    their own row; BLOCKED by name 0.53 ms, STREAM 0.26).
+         *    their own row; BLOCKED by name 0.40-0.53 ms, STREAM 0.26);
+         *  - more than one bin in twenty is cut: the rows are uneven throughout, not here and there (the same graph without
+         *    its 16 384 most popular columns: no crowded cell any more, but 232 of 2048 bins cut, 449 us where the CSR
+         *    kernel's gathers are no worse than on the whole graph).
          */
         if (auto_choice) {
             size_t nonempty = 0;
@@ -194,7 +197,7 @@ int spmv_blocked_plan_build(int *cnt, int64_t nnz, int auto_choice, spmv_blocked
                 nonempty += cnt[id] != 0;
             const double mean_cell = (double)nnz / (double)ncells;
             const double expected = (double)ncells * (1.0 - exp(-mean_cell));
-            if ((double)nonempty < 0.6 * expected || max_piece > 3 * share) {
+            if ((double)nonempty < 0.6 * expected || max_piece > 3 * share || (int64_t)n_join * 20 > B) {
                 rc = -2;
                 goto out;
             }

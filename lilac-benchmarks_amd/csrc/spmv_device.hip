@@ -720,6 +720,7 @@ static int ensure_blocked(spmv_hip_matrix *m, bool auto_choice)
         spmv_set_error("out of memory for the BLOCKED layout");
     if (rc)
         return rc;
+    m->db.runs = m->st.max_len > 2 * (int64_t)m->db.S; /* a row with two entries per stripe on average: runs of one row's products */
     m->device_bytes += m->db.bytes;
     m->have_blocked = true;
     return 0;

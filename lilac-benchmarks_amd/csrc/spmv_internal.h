@@ -234,6 +234,7 @@ typedef struct spmv_dev_blocked {
     int *jn;           /* [n_join * 3] cut bins: bin, first slot, slots                                             */
     double *part;      /* [n_slots * RB] partial sums of the pieces of cut bins: scratch                           */
     int elem, rows, cols, S, wcols, W, RB, B, n_wg, n_pieces, n_slots, n_join;
+    int runs;          /* phase 2 sums runs of one row's products before the LDS add: set when a row is long enough to have them */
     int64_t nnz, n1, n2;
     size_t bytes;
 } spmv_dev_blocked;

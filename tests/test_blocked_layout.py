@@ -242,3 +242,11 @@ def test_blocked_builder_declines_what_does_not_suit(planlib):
     assert build(planlib, rs2, crowded, 8, auto=1)[0] == -2
     rc, p, padded, cell = build(planlib, rs2, crowded, 8, auto=0)
     assert rc == 0 and p["n_join"] >= 1
+    # uneven throughout: a fifth of the bins hold three times the rest -- every one of them would be cut
+    lens3 = lens.copy()
+    lens3[: rows // 5] = 15
+    rs3 = np.concatenate(([1], 1 + np.cumsum(lens3))).astype(np.int32)
+    uneven = rng.integers(1, rows + 1, int(lens3.sum())).astype(np.int32)
+    assert build(planlib, rs3, uneven, 8, auto=1)[0] == -2
+    rc, p, padded, cell = build(planlib, rs3, uneven, 8, auto=0)
+    assert rc == 0 and p["n_join"] * 20 > p["B"]

@@ -15,6 +15,14 @@ for size in sizes:
     sb = pkg.callers.sb_generate(size)
     rs, ci, a = sb.arrays()
     a = a.astype(dtype)
+    for extra in [int(v[7:]) for v in sys.argv[1:] if v.startswith("--plant")]:  # one row gets `extra` more entries (scattered)
+        r0 = sb.rows // 3
+        p0 = int(rs[r0 + 1]) - 1
+        rng = np.random.default_rng(extra)
+        ci = np.concatenate([ci[:p0], rng.integers(1, sb.rows + 1, extra).astype(np.int32), ci[p0:]])
+        a = np.concatenate([a[:p0], rng.standard_normal(extra).astype(dtype), a[p0:]])
+        rs = np.array(rs).copy()
+        rs[r0 + 1:] += extra
     dm = be.matrix(a, rs, ci, sb.rows)
     inf = dm.info()
     x = np.random.default_rng(1).standard_normal(inf["cols"] + 2).astype(dtype)
