@@ -1409,6 +1409,30 @@ def test_auto_takes_blocked_for_scattered_columns_only(pkg, backend, oracle):
                           np.float64, "banded, BLOCKED by name", CSR)
     finally:
         m.close()
+    # a power-law graph (R-MAT 2^20 x 16: x = 8.4 MB, so nominated), as generated and with rows and columns scrambled in groups of
+    # 8: a crowded cell the first, one bin in five cut the second -- both declined (BLOCKED by name is 2 x / 1.4 x behind STREAM)
+    g = pkg.callers.graph_rmat(20, 16)
+    rs_g, ci_g, a_g = (np.array(v) for v in g.arrays())
+    pkg.callers.free(g)
+    n = rs_g.size - 1
+
+    def scramble(m, mult):
+        m8 = (m + 7) // 8
+        while np.gcd(mult, m8) != 1:
+            mult += 1
+        idx = np.arange(m8 * 8, dtype=np.int64)
+        return ((idx // 8) * mult % m8) * 8 + idx % 8
+    rowid_g = np.repeat(np.arange(n, dtype=np.int64), np.diff(rs_g))
+    nr, nc = scramble(n, 0x9E3779B1 % (1 << 30))[rowid_g], scramble(int(ci_g.max()), 0x85EBCA6B % (1 << 30))[ci_g.astype(np.int64) - 1]
+    order = np.argsort(nr, kind="stable")
+    rs_p = np.concatenate(([1], 1 + np.cumsum(np.bincount(nr, minlength=n)[:n]))).astype(np.int32)
+    ci_p, a_p = (nc[order] + 1).astype(np.int32), a_g[order]
+    for name, (r_, c_, a_) in (("rmat20", (rs_g, ci_g, a_g)), ("rmat20 scrambled", (rs_p, ci_p, a_p))):
+        m = backend.matrix(a_, r_, c_, n)
+        try:
+            assert m.info()["plan"] == pkg.PLAN_STREAM, (name, m.info())
+        finally:
+            m.close()
     # scattered columns, one row with 600 000 entries more: its bin is cut into pieces whose partial sums a third launch adds
     r0, extra = rows // 3, 600_000
     p = int(rs[r0 + 1]) - 1
