@@ -1452,6 +1452,42 @@ def test_auto_takes_blocked_for_scattered_columns_only(pkg, backend, oracle):
         m.close()
 
 
+BLOCKED_PARTS_SCRIPT = """
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, pkgload, rowtol
+from oracle.oracle import Oracle
+p = pkgload.load_package(); be = p.Backend(); o = Oracle()
+sb = p.callers.sb_generate(130)
+rs, ci, a = (np.array(v) for v in sb.arrays())
+rows = sb.rows
+x = np.random.default_rng(9).standard_normal(rows)
+y = np.full(rows, np.nan)
+for _ in range(4):  # a copy whose values change before it has served three products is taken for volatile (PFOLD) and loses its layout
+    be.harness(y, a, x, rs, ci, rows)
+ref = o.spmv(a, x, rs, ci, rows); ab = o.absum(a, x, rs, ci, rows)
+ok = bool(np.all(np.abs(y - ref) <= rowtol.row_tolerance(np.diff(rs), ab, 2.0 ** -53)))
+a[::7] *= 1.5  # the values change, the structure stays: a value refresh packs the layouts again
+be.harness(y, a, x, rs, ci, rows)
+ref = o.spmv(a, x, rs, ci, rows); ab = o.absum(a, x, rs, ci, rows)
+ok2 = bool(np.all(np.abs(y - ref) <= rowtol.row_tolerance(np.diff(rs), ab, 2.0 ** -53)))
+s = be.stats()
+print("BLKPARTS", int(ok), int(ok2), p.abi.PLAN_NAMES[be.abi_matrix_info()["plan"]], s["uploads"], s["value_refreshes"])
+"""
+
+
+@pytest.mark.parametrize("parts", ["1", "2"])
+def test_blocked_through_the_abi_whole_and_in_row_partitions(parts):
+    """SparseBench 130^3 through spmv_harness_ in a fresh process: the automatic choice gives BLOCKED to the whole matrix and
+    to each of two row partitions (their own layouts and scratch; x whole on every part), results within the bar, and an edit
+    of a[] alone is answered by a value refresh that packs the layouts again."""
+    out = _run_py(BLOCKED_PARTS_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__)),
+                  {"SPMV_HIP_PARTS": parts, "SPMV_HIP_DISPATCH": "device"}).split()
+    i = out.index("BLKPARTS")
+    assert out[i + 1:i + 4] == ["1", "1", "blocked"], out
+    assert int(out[i + 4]) == 1 and int(out[i + 5]) == 1, out
+
+
 def test_relayouts_give_their_memory_back(pkg, backend):
     """Every re-laid-out plan allocates a second copy (and scratch) on the device; creating, refreshing and closing such
     matrices over and over must leave the device's free memory where it was (hipMemGetInfo)."""
