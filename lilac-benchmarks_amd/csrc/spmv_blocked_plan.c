@@ -22,7 +22,9 @@ int spmv_blocked_lds_elems(int elem_size) { return elem_size == 8 ? 20480 : 3276
  */
 static int choose_bin_rows(int rows)
 {
-    const int64_t slots = 2048, rb_max = SPMV_BLOCKED_MAX_BIN_ROWS;
+    /* 1946 of the 2048 slots of a round: one bin in twenty may be cut (more and the builder declines) without its pieces
+     * spilling into another round */
+    const int64_t slots = 1946, rb_max = SPMV_BLOCKED_MAX_BIN_ROWS;
     const int64_t rounds = (rows + slots * rb_max - 1) / (slots * rb_max);
     int64_t rb = (rows + slots * rounds - 1) / (slots * rounds);
     rb = (rb + 255) / 256 * 256;
