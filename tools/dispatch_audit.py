@@ -60,9 +60,13 @@ def main():
                 line = "%8d %6d %9d | %-8s %8.2f | best %-8s %8.2f | %s" % (
                     rows, mean, inf["nnz"], auto_plan, auto_us, best, res[best],
                     " ".join("%s=%.1f" % kv for kv in sorted(res.items())))
-                same = auto_plan.replace("vector", "vec") == best  # AUTO chose the plan that came out best: a gap is timing noise
-                flag = auto_us > 1.10 * res[best] and not same
-                print(line + ("   <-- %.0f %% behind (cols=%d)" % ((auto_us / res[best] - 1) * 100, cols) if flag else ""),
+                key = auto_plan.replace("vector", "vec")
+                same = key == best  # AUTO chose the plan that came out best: a gap is timing noise
+                # the plan AUTO chose was also timed as a candidate: the better of the two timings is what the choice costs
+                # (at 3 us two timings of one kernel differ by 10 %)
+                auto_cost = min(auto_us, res.get(key, auto_us))
+                flag = auto_cost > 1.10 * res[best] and not same
+                print(line + ("   <-- %.0f %% behind (cols=%d)" % ((auto_cost / res[best] - 1) * 100, cols) if flag else ""),
                       flush=True)
                 if flag:
                     worst.append(line)
@@ -122,7 +126,7 @@ def main():
         dm.set_plan(pkg.PLAN_AUTO, 0)
         auto_us = min(auto_us, t2())
         best = min(res, key=res.get)
-        flag = auto_us > 1.10 * res[best] and auto_plan != best
+        flag = min(auto_us, res.get(auto_plan, auto_us)) > 1.10 * res[best] and auto_plan != best
         print("%-16s rows=%d nnz=%d len %d..%d | %-8s %8.2f | best %-8s %8.2f | %s%s" % (
             name, rows, inf["nnz"], inf["min_row_len"], inf["max_row_len"], auto_plan, auto_us, best, res[best],
             " ".join("%s=%.1f" % kv for kv in sorted(res.items())),
