@@ -35,7 +35,7 @@ static uint64_t rnd(void)
 int main(int argc, char **argv)
 {
     const int cases = argc > 1 ? atoi(argv[1]) : 2000;
-    long built[3] = {0, 0, 0}, declined[3] = {0, 0, 0};
+    long built[4] = {0, 0, 0, 0}, declined[4] = {0, 0, 0, 0};
     for (int t = 0; t < cases; ++t) {
         /* mostly small shapes; every 25th is large enough for the builders' passes to split over threads */
         const int rows = (t % 25 == 24) ? 9000 + (int)(rnd() % 30000) : 1 + (int)(rnd() % 700);
@@ -107,9 +107,44 @@ int main(int argc, char **argv)
             fprintf(stderr, "tiled rc=%d\n", rc);
             return 1;
         }
+        /* BLOCKED's host side (spmv_blocked_plan.c): geometry, then the plan from one count per (stripe, bin) cell */
+        {
+            const int rb_sel[] = {0, 64, 128, 1024, 2560};
+            spmv_blocked_plan g;
+            if (spmv_blocked_geometry(rows, cols, elem, rb_sel[rnd() % 5], &g) == 0) {
+                int *cnt = (int *)calloc((size_t)g.S * g.B, sizeof(int));
+                if (!cnt)
+                    return 1;
+                for (int r = 0; r < rows; ++r)
+                    for (int j = rowstr[r] - 1; j < rowstr[r + 1] - 1; ++j)
+                        cnt[(size_t)((colidx[j] - 1) / g.wcols) * g.B + r / g.RB]++;
+                rc = spmv_blocked_plan_build(cnt, nnz, (int)(rnd() & 1), &g);
+                if (rc == 0) {
+                    /* every cell inside both streams, the pieces' windows ascending up to the end of phase 2's */
+                    int bad = g.n1 % SPMV_BLOCKED_WIN || g.n2 % SPMV_BLOCKED_WIN || g.c1q[(size_t)g.S * g.B] != (uint32_t)(g.n1 / 4) ||
+                              g.pw[g.n_pieces] != (int)(g.n2 / SPMV_BLOCKED_WIN) || g.n_pieces < g.B;
+                    for (size_t id = 0; id < (size_t)g.S * g.B && !bad; ++id)
+                        bad = (int64_t)g.c1q[id] * 4 + cnt[id] > g.n1 || (int64_t)g.c2q[id] * 4 + cnt[id] > g.n2;
+                    for (int i = 0; i < g.n_pieces && !bad; ++i)
+                        bad = g.pw[i] > g.pw[i + 1] || g.pb[i] < 0 || g.pb[i] >= g.B || g.ps[i] >= g.n_slots;
+                    if (bad) {
+                        fprintf(stderr, "case %d: inconsistent BLOCKED plan\n", t);
+                        return 1;
+                    }
+                    built[3]++;
+                    spmv_blocked_plan_free(&g);
+                } else if (rc == -2 || (rc == -1 && nnz == 0)) {
+                    declined[3]++;
+                } else {
+                    fprintf(stderr, "case %d: spmv_blocked_plan_build rc=%d\n", t, rc);
+                    return 1;
+                }
+                free(cnt);
+            }
+        }
         free(rowstr), free(colidx), free(a);
     }
-    printf("layout_fuzz: %d cases; striped %ld built / %ld declined; tiled %ld / %ld\n", cases, built[0], declined[0],
-           built[2], declined[2]);
+    printf("layout_fuzz: %d cases; striped %ld built / %ld declined; tiled %ld / %ld; blocked plan %ld / %ld\n", cases, built[0],
+           declined[0], built[2], declined[2], built[3], declined[3]);
     return 0;
 }
