@@ -434,6 +434,8 @@ extern "C" int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, 
     if (spmv_blocked_geometry(rows, cols, elem_size, g_blk_bin_rows.load(std::memory_order_relaxed), &g))
         return -2;
     const int S = g.S, wcols = g.wcols, W = g.W, RB = g.RB, B = g.B;
+    if (RB < 1024 || RB % 256) /* k_blk_bins is instantiated for 1024, 1280 ... 2560 rows per bin */
+        return -2;
     const size_t ncells = (size_t)S * (size_t)B;
     int *d_cnt = nullptr, *h_cnt = nullptr;
     unsigned int *d_c1q = nullptr, *d_c2q = nullptr;
