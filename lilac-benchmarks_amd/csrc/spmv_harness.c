@@ -995,7 +995,12 @@ static void refresh_values(slot *sl, const void *a, const int *colidx)
             slot_arm_guard(sl, 0, 2);
         }
     } else {
-        guard_free(&sl->g[0]); /* written, hence disarmed; or a stale saved copy */
+        /* a write that faulted has disarmed the guard already; an edit of the saved head / tail fragment alone has not:
+         * the interior pages are still read-only and must go writable before the record of them is forgotten (a volatile
+         * matrix never re-arms, and the caller's next interior write would find no guard to let it through) */
+        if (sl->g[0].armed)
+            disarm_cascade(&sl->g[0], GUARD_WRITTEN);
+        guard_free(&sl->g[0]);
         if (short_lived || sl->probing) {
             sl->probe_every = sl->probing && sl->probe_every < 4096 ? 2 * sl->probe_every : (sl->probing ? 4096 : CHURN_PROBE_CALLS);
             sl->values_volatile = 1;

@@ -160,14 +160,18 @@ __global__ void __launch_bounds__(SPMV_WG) k_vector(const int *__restrict__ rowp
 }
 
 /* ================================ k_stream ====================================== */
-template <typename T, bool NT>
+/* DIAG: the debug build's timing-only twin (tuning key 6; results are wrong when a bit is set): 1 = no phase 2 (what do
+ * the loads, the gathers and the LDS parking cost alone), 2 = every gather goes to the first KiB of x (what do the
+ * gather MISSES cost), 4 = no row pointers either.  The shipped instantiation (DIAG = false) contains none of it. */
+template <typename T, bool NT, bool DIAG>
 __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
                                                     const int *__restrict__ rowptr,
                                                     const int *__restrict__ colidx,
                                                     const T *__restrict__ val,
                                                     const T *__restrict__ xm1, T *__restrict__ y,
-                                                    int nblk, int per_xcd)
+                                                    int nblk, int per_xcd, int abl_arg)
 {
+    const int abl = DIAG ? abl_arg : 0;
     using VT = typename Vec16<T>::val_t;
     using IT = typename Vec16<T>::idx_t;
     constexpr int E = Vec16<T>::E;
@@ -206,14 +210,15 @@ __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
         c[k] = ld<IT, NT>(reinterpret_cast<const IT *>(colidx + jl));
         v[k] = ld<VT, NT>(reinterpret_cast<const VT *>(val + jl));
     }
-    for (int i = tid; i <= nrows; i += SPMV_WG)
-        s_rp[i] = rowptr[r0 + i] - base;
+    if (!(abl & 4))
+        for (int i = tid; i <= nrows; i += SPMV_WG)
+            s_rp[i] = rowptr[r0 + i] - base;
     T xg[ROUNDS][E];
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k)
 #pragma unroll
         for (int i = 0; i < E; ++i)
-            xg[k][i] = xm1[c[k][i]];
+            xg[k][i] = xm1[(abl & 2) ? 1 + (c[k][i] & 127) : c[k][i]];
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k) {
         VT p;
@@ -223,6 +228,11 @@ __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
         *reinterpret_cast<VT *>(&s_prod[(k * SPMV_WG + tid) * E]) = p;
     }
     __syncthreads();
+    if (abl & 1) { /* timing only */
+        if (tid < nrows)
+            y[r0 + tid] = s_prod[tid];
+        return;
+    }
 
     /* ---- phase 2: lane groups reduce whole rows out of LDS ---- */
     /* G lanes per row, block-uniform: as many as fill the workgroup in one pass,
@@ -1148,8 +1158,19 @@ int spmvk_stream(const spmv_dev_csr *m, const int *blk, int nblk, const void *x,
     const int per = g_tune_xcd ? (nblk + 7) / 8 : 0;
     const int grid = per ? per * 8 : nblk;
 #define SPMV_LS(T, NT)                                                                          \
-    hipLaunchKernelGGL((k_stream<T, NT>), dim3(grid), dim3(SPMV_WG), 0, st, blk, m->rowptr,     \
-                       m->colidx, (const T *)m->val, xm1_of<T>(x), (T *)y, nblk, per)
+    hipLaunchKernelGGL((k_stream<T, NT, false>), dim3(grid), dim3(SPMV_WG), 0, st, blk, m->rowptr, \
+                       m->colidx, (const T *)m->val, xm1_of<T>(x), (T *)y, nblk, per, 0)
+#ifdef SPMV_HIP_DEBUG_BUILD
+    if (g_tune_abl != 0) { /* the instrumented twin, on request only */
+        if (m->elem_size == 8)
+            hipLaunchKernelGGL((k_stream<double, false, true>), dim3(grid), dim3(SPMV_WG), 0, st, blk, m->rowptr, m->colidx,
+                               (const double *)m->val, xm1_of<double>(x), (double *)y, nblk, per, g_tune_abl);
+        else
+            hipLaunchKernelGGL((k_stream<float, false, true>), dim3(grid), dim3(SPMV_WG), 0, st, blk, m->rowptr, m->colidx,
+                               (const float *)m->val, xm1_of<float>(x), (float *)y, nblk, per, g_tune_abl);
+        return launch_status();
+    }
+#endif
     if (m->elem_size == 8) {
         if (g_tune_nt)
             SPMV_LS(double, true);

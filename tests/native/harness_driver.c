@@ -373,6 +373,45 @@ int main(int argc, char **argv)
         printf("ok value refreshes (%s)\n", policy);
     }
 
+    /* an edit of the saved head fragment ALONE (a[0] lies on the partial first page, which is compared,
+     * not protected) on a copy younger than 3 products: the values go volatile and the guard record of `a` is dropped --
+     * its interior pages must go writable with it, or the caller's next interior write dies on a fault nobody owns. */
+    if (strcmp(policy, "pointer") && strcmp(policy, "off")) {
+        csr fm = make(6000, 5000, 40);
+        int fr = fm.rows;
+        spmv_hip_reset_stats();
+        spmv_harness_(y, fm.a, x, fm.rowstr, fm.colidx, &fr);
+        check(&fm, x, y);
+        fm.a[0] += 1.0;
+        spmv_harness_(y, fm.a, x, fm.rowstr, fm.colidx, &fr);
+        check(&fm, x, y);
+        fm.a[fm.nnz / 2] += 1.0; /* an interior page: read-only until the fix */
+        fm.a[fm.nnz - 1] += 1.0; /* the tail fragment */
+        spmv_harness_(y, fm.a, x, fm.rowstr, fm.colidx, &fr);
+        check(&fm, x, y);
+        spmv_hip_get_stats(&s);
+        EXPECT(s.uploads == 1 && s.value_refreshes == 2 && s.invalidations == 0);
+        /* the same on a copy that has lived (>= 3 products): the watch is re-armed, and a later interior write faults
+         * into OUR handler and is seen */
+        spmv_hip_release();
+        spmv_hip_reset_stats();
+        for (int k = 0; k < 4; ++k)
+            spmv_harness_(y, fm.a, x, fm.rowstr, fm.colidx, &fr);
+        fm.a[0] -= 0.25;
+        spmv_harness_(y, fm.a, x, fm.rowstr, fm.colidx, &fr);
+        check(&fm, x, y);
+        for (int k = 0; k < 3; ++k)
+            spmv_harness_(y, fm.a, x, fm.rowstr, fm.colidx, &fr);
+        fm.a[fm.nnz / 3] += 2.0;
+        spmv_harness_(y, fm.a, x, fm.rowstr, fm.colidx, &fr);
+        check(&fm, x, y);
+        spmv_hip_get_stats(&s);
+        EXPECT(s.uploads == 1 && s.value_refreshes == 2 && s.invalidations == 0);
+        spmv_hip_release();
+        free(fm.rowstr), free(fm.colidx), free(fm.a);
+        printf("ok fragment-only edit, then an interior write (%s)\n", policy);
+    }
+
     /* degenerate shapes: no rows, all rows empty */
     {
         int zero = 0, three = 3;

@@ -501,6 +501,50 @@ def test_abi_policies_in_a_fresh_process(env, uploads, exact):
     assert int(out[6]) == (0 if env.get("SPMV_HIP_CACHE") in ("pointer", "off") else 1), out
 
 
+FRAGMENT_SCRIPT = """
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, pkgload, matgen, rowtol
+from oracle.oracle import Oracle
+p = pkgload.load_package(); be = p.Backend(); o = Oracle()
+rs, ci, a0 = matgen.npb_like(52, 4000, 120)
+buf = np.empty(a0.size + 1024)
+off = 1 if buf.ctypes.data %% 4096 == 0 else 0     # a[0] must lie on a PARTIAL first page (compared, not protected)
+a = buf[off:off + a0.size]; a[:] = a0
+assert a.ctypes.data %% 4096 != 0
+rows = 4000; x = np.random.default_rng(52).standard_normal(rows); y = np.empty(rows); lens = np.diff(rs)
+def ok():
+    ref = o.spmv(a, x, rs, ci, rows); ab = o.absum(a, x, rs, ci, rows)
+    return bool(np.all(np.abs(y - ref) <= rowtol.row_tolerance(lens, ab, 2.0**-53)))
+res = []
+for young in (1, 0):
+    be.release(); be.reset_stats()
+    for _ in range(1 if young else 4):
+        be.harness(y, a, x, rs, ci, rows)
+    a[0] += 1.0                      # the saved fragment alone
+    be.harness(y, a, x, rs, ci, rows); res.append(ok())
+    a[a.size // 2] += 1.0            # an interior page
+    a[-1] += 1.0
+    be.harness(y, a, x, rs, ci, rows); res.append(ok())
+    s = be.stats(); res.append(s["uploads"] == 1 and s["value_refreshes"] == 2 and s["invalidations"] == 0)
+be.release()
+print("FRAGMENT", int(all(res)), res)
+"""
+
+
+def test_a_fragment_only_edit_does_not_leave_read_only_pages_behind():
+    """`a[0] += 1` on a cached copy touches only the partial first page of `a` (saved and compared,
+    not protected); the value refresh that answers it used to forget the guard while its interior pages were still
+    PROT_READ -- on a copy younger than 3 products the values then go volatile, nothing re-arms, and the caller's next
+    interior write faulted with no guard to claim it (SIGSEGV, rc 139).  Fresh process: a fault must not take pytest down."""
+    code = FRAGMENT_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__))
+    proc = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          env=dict(os.environ, SPMV_HIP_DISPATCH="device"), timeout=600)
+    assert proc.returncode == 0, (proc.returncode, proc.stdout[-2000:] + proc.stderr[-3000:])
+    line = [l for l in proc.stdout.splitlines() if l.startswith("FRAGMENT")][0]
+    assert line.split()[1] == "1", line
+
+
 DISPATCH_SCRIPT = """
 import sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
