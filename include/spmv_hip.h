@@ -32,6 +32,9 @@ enum {
     SPMV_HIP_PLAN_STRIPED = 6, /* 2-D: a workgroup = (group of column stripes, row block); one stripe */
                                /* of x in LDS at a time, row sums carried in registers across the  */
                                /* group, one partial sum per (group, row), added in group order     */
+    SPMV_HIP_PLAN_HUB = 8,     /* the CSR stream in fixed chunks, segmented wave scan, the most referenced ("hub") columns   */
+                               /* of x in LDS: for power-law graphs (bfs, pagerank), where a few thousand columns take most */
+                               /* of the gathers; values are read from the CSR copy itself                                  */
     SPMV_HIP_PLAN_BLOCKED = 7  /* two phases over (column stripe, row bin) cells: a workgroup keeps a    */
                                /* stripe of x in LDS and writes the PRODUCTS binned by row; one wave per */
                                /* bin adds them in LDS.  No gathers from memory: for short rows with     */

@@ -6,7 +6,7 @@ measurement.  It deliberately contains no compute path of its own and never touc
 `oracle/`: if the library is missing or no GPU is present, calls fail loudly.
 """
 from .build import build_all, LIB_DIR, lib_path  # noqa: F401
-from .abi import Backend, Matrix, Info, Stats, PLAN_AUTO, PLAN_ORDERED, PLAN_STREAM, PLAN_VECTOR, PLAN_BINNED, PLAN_TILED, PLAN_STRIPED, PLAN_BLOCKED  # noqa: F401
+from .abi import Backend, Matrix, Info, Stats, PLAN_AUTO, PLAN_ORDERED, PLAN_STREAM, PLAN_VECTOR, PLAN_BINNED, PLAN_TILED, PLAN_STRIPED, PLAN_BLOCKED, PLAN_HUB  # noqa: F401
 from . import npb  # noqa: F401
 from . import callers  # noqa: F401
 

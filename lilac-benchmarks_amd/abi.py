@@ -7,8 +7,8 @@ import numpy as np
 
 from .build import lib_path
 
-PLAN_AUTO, PLAN_ORDERED, PLAN_STREAM, PLAN_VECTOR, PLAN_BINNED, PLAN_TILED, PLAN_STRIPED, PLAN_BLOCKED = 0, 1, 2, 3, 4, 5, 6, 7
-PLAN_NAMES = {0: "auto", 1: "ordered", 2: "stream", 3: "vector", 4: "binned", 5: "tiled", 6: "striped", 7: "blocked"}
+PLAN_AUTO, PLAN_ORDERED, PLAN_STREAM, PLAN_VECTOR, PLAN_BINNED, PLAN_TILED, PLAN_STRIPED, PLAN_BLOCKED, PLAN_HUB = 0, 1, 2, 3, 4, 5, 6, 7, 8
+PLAN_NAMES = {0: "auto", 1: "ordered", 2: "stream", 3: "vector", 4: "binned", 5: "tiled", 6: "striped", 7: "blocked", 8: "hub"}
 
 c_int_p = ctypes.POINTER(ctypes.c_int)
 

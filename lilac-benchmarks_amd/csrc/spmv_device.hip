@@ -32,6 +32,7 @@
 
 extern "C" void spmvk_set_tuning(int key, int value);
 extern "C" void spmvk_blocked_set_bin_rows(int per_xcd);
+extern "C" void spmvk_hub_set_min_cover(int per_cent);
 extern "C" int spmvk_get_tuning_xcd(void);
 static bool g_tune_xcd_enabled() { return spmvk_get_tuning_xcd() != 0; }
 
@@ -126,6 +127,10 @@ struct spmv_hip_matrix {
     spmv_dev_blocked db{};
     int striped_rc = 0;
     spmv_dev_striped ds{};
+    /* HUB (built on demand, on the device; holds no values of its own: a value refresh leaves it alone) */
+    bool have_hub = false;
+    int hub_rc = 0;
+    spmv_dev_hub dh{};
 };
 
 extern "C" {
@@ -305,8 +310,18 @@ int spmvd_copy_words_async(int device, void *dst_dev, const void *src_devptr, si
 
 static void free_relayouts(spmv_hip_matrix *m);
 
+static void free_hub(spmv_hip_matrix *m)
+{
+    if (m->have_hub) {
+        m->device_bytes -= m->dh.bytes;
+        spmv_hub_free(&m->dh);
+        m->have_hub = false;
+    }
+}
+
 static void free_plans(spmv_hip_matrix *m)
 {
+    free_hub(m);
     if (m->d_blk)
         (void)hipFree(m->d_blk);
     if (m->d_seg)
@@ -726,6 +741,36 @@ static int ensure_blocked(spmv_hip_matrix *m, bool auto_choice)
     return 0;
 }
 
+static int ensure_hub(spmv_hip_matrix *m, bool auto_choice)
+{
+    if (m->have_hub)
+        return 0;
+    int rc = spmv_hub_build_device(m->d_rowptr, m->h_rowstr_local, m->d_col, m->d_val, m->rows, m->cols, m->elem, m->nnz,
+                                   auto_choice ? 1 : 0, g_dev[m->device].stream, &m->dh);
+    if (rc == 0 && take_injected_oom()) {
+        spmv_hub_free(&m->dh);
+        rc = -3;
+    }
+    m->hub_rc = rc;
+    if (rc == -2)
+        spmv_set_error("matrix not representable in the HUB layout (2^30 columns or more) or not suited to it (too few entries in hub columns)");
+    else if (rc == -3)
+        spmv_set_error("out of memory for the HUB layout");
+    if (rc)
+        return rc;
+    m->device_bytes += m->dh.bytes;
+    m->have_hub = true;
+    return 0;
+}
+
+/* AUTO's last question, asked when the CSR kernel would otherwise serve a matrix that is large enough to care: do a few
+ * thousand columns take a good share of the gathers?  (R-MAT 2^20: STREAM 107 us, HUB see profiles/r04_hub_*.log.)  The
+ * builder counts the references per column and declines when they do not. */
+static bool hub_nominated(const spmv_hip_matrix *m)
+{
+    return m->nnz >= 2000000 && (int64_t)m->cols * m->elem >= (2ll << 20) && m->cols < (1 << 30);
+}
+
 spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const int *colidx, int rows,
                                         int elem_size, int device, int row_begin, int row_end,
                                         int cols_hint)
@@ -892,6 +937,15 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
             m->param = m->db.wcols;
         }
     }
+    if (m->plan == SPMV_HIP_PLAN_STREAM && g_relayout && hub_nominated(m)) {
+        int rc = ensure_hub(m, true);
+        if (rc == 0) {
+            m->plan = SPMV_HIP_PLAN_HUB;
+            m->param = m->dh.K;
+        } else if (rc != -2 && rc != -3) {
+            FAIL();
+        }
+    }
     if (m->plan == SPMV_HIP_PLAN_BINNED && ensure_bins(m))
         FAIL();
 #undef FAIL
@@ -925,11 +979,15 @@ int spmv_hip_matrix_refresh_values(spmv_hip_matrix *m, const void *a, const int 
             rc = ensure_striped(m, colidx ? a : nullptr, colidx, m->first, false);
         else if (was_tiled)
             rc = ensure_tiled(m, colidx ? a : nullptr, colidx, m->first, false);
-        if (rc == -2 || rc == -3) { /* cannot happen for a layout that existed a moment ago, short of memory: the CSR kernels serve */
+        if (rc) {
+            /* -2 / -3 cannot happen for a layout that existed a moment ago, short of memory; any other failure is reported.
+             * Either way the re-laid-out copy is gone and the CSR copy holds the new values: the CSR kernels serve from
+             * here on, also for a caller that ignores the error (the plan used to stay BLOCKED with no layout
+             * behind it, and the next product returned 0 without writing y) */
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
-        } else if (rc) {
-            return -1;
+            if (rc != -2 && rc != -3)
+                return -1;
         }
     }
     return 0;
@@ -966,6 +1024,20 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
                 m->param = m->db.wcols;
             }
         }
+        if (m->plan == SPMV_HIP_PLAN_STREAM && hub_nominated(m)) {
+            if (ensure_hub(m, true) == 0) {
+                m->plan = SPMV_HIP_PLAN_HUB;
+                m->param = m->dh.K;
+            } else if (m->hub_rc != -2 && m->hub_rc != -3) {
+                return -1;
+            }
+        }
+        break;
+    case SPMV_HIP_PLAN_HUB:
+        if (ensure_hub(m, false))
+            return -1;
+        m->plan = plan;
+        m->param = m->dh.K;
         break;
     case SPMV_HIP_PLAN_BLOCKED:
         if (ensure_blocked(m, false))
@@ -1021,6 +1093,7 @@ static int n_launches(const spmv_hip_matrix *m)
     case SPMV_HIP_PLAN_STRIPED: return m->ds.NG > 1 ? 2 : 1;
     case SPMV_HIP_PLAN_BLOCKED: return m->db.n_join > 0 ? 3 : 2; /* + k_blk_join when a bin was cut */
     case SPMV_HIP_PLAN_STREAM: return 1 + longk;
+    case SPMV_HIP_PLAN_HUB: return 1 + (m->dh.K > 0) + (m->dh.n_fix > 0 || m->dh.n_empty > 0); /* k_hub_pack, k_hub, k_hub_fix */
     case SPMV_HIP_PLAN_BINNED: {
         int n = longk;
         for (int b = 0; b < SPMV_NBINS; ++b)
@@ -1049,6 +1122,7 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out)
     out->n_blocks = m->plan == SPMV_HIP_PLAN_TILED     ? m->dt.B
                     : m->plan == SPMV_HIP_PLAN_STRIPED ? m->ds.n_wg
                     : m->plan == SPMV_HIP_PLAN_BLOCKED ? m->db.n_wg
+                    : m->plan == SPMV_HIP_PLAN_HUB     ? m->dh.n_chunks
                                                        : m->sp.nblk;
     out->n_long_rows = m->sp.n_long_rows;
     out->n_launches = n_launches(m);
@@ -1097,15 +1171,25 @@ int spmv_hip_spmv_device(spmv_hip_matrix *m, const void *x_dev, void *y_dev, voi
     int rc = 0;
     switch (m->plan) {
     case SPMV_HIP_PLAN_ORDERED: rc = spmvk_ordered(&d, x_dev, y_dev, st); break;
-    case SPMV_HIP_PLAN_BLOCKED: rc = spmvk_blocked(&m->db, x_dev, y_dev, st); break;
-    case SPMV_HIP_PLAN_STRIPED:
-    case SPMV_HIP_PLAN_TILED:
-        if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0) {
-            rc = m->plan == SPMV_HIP_PLAN_TILED ? spmvk_tiled(&m->dt, x_dev, y_dev, st)
-                                                : spmvk_striped(&m->ds, x_dev, y_dev, st, nullptr, nullptr);
+    case SPMV_HIP_PLAN_HUB:
+        if (m->have_hub) {
+            rc = spmvk_hub(&m->dh, x_dev, y_dev, st);
             break;
         }
-        /* k_tiled stages x with 16-byte loads; a misaligned x goes to the row-segment kernel */
+        rc = spmvk_stream(&d, m->d_blk, m->sp.nblk, x_dev, y_dev, st);
+        if (!rc && m->sp.nseg > 0)
+            rc = spmvk_long(&d, m->d_seg, m->sp.nseg, m->d_lrow, m->sp.nlrow, m->d_partials, x_dev, y_dev, st);
+        break;
+    case SPMV_HIP_PLAN_BLOCKED:
+    case SPMV_HIP_PLAN_STRIPED:
+    case SPMV_HIP_PLAN_TILED:
+        if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0 && (m->plan != SPMV_HIP_PLAN_BLOCKED || m->have_blocked)) {
+            rc = m->plan == SPMV_HIP_PLAN_TILED     ? spmvk_tiled(&m->dt, x_dev, y_dev, st)
+                 : m->plan == SPMV_HIP_PLAN_BLOCKED ? spmvk_blocked(&m->db, x_dev, y_dev, st)
+                                                    : spmvk_striped(&m->ds, x_dev, y_dev, st, nullptr, nullptr);
+            break;
+        }
+        /* the three re-laid-out plans stage x with 16-byte loads; a misaligned x goes to the row-segment kernel */
         rc = spmvk_stream(&d, m->d_blk, m->sp.nblk, x_dev, y_dev, st);
         if (!rc && m->sp.nseg > 0)
             rc = spmvk_long(&d, m->d_seg, m->sp.nseg, m->d_lrow, m->sp.nlrow, m->d_partials, x_dev,
@@ -1432,6 +1516,8 @@ void spmv_hip_set_tuning(int key, int value)
         g_stripe_xcd_bias = value; /* STRIPED: per mille of weight moved from even-XCD workgroups to odd-XCD ones */
     else if (key == 18)
         spmvk_blocked_set_bin_rows(value); /* BLOCKED: rows per bin of layouts built from now on */
+    else if (key == 21)
+        spmvk_hub_set_min_cover(value); /* HUB: per cent of the entries that must hit a hub column for AUTO to keep the plan */
     else if (key == 17 && value >= 0 && value <= 2)
         g_striped_builder = value; /* 0: the device builds the STRIPED layout (the host when it must), 1: host, 2: device or fail */
     else if (key == 15 && value >= 0 && value <= 2)

@@ -553,8 +553,10 @@ static void lazy_init(void)
             G.plan = SPMV_HIP_PLAN_STRIPED;
         else if (!strcmp(v, "blocked"))
             G.plan = SPMV_HIP_PLAN_BLOCKED;
+        else if (!strcmp(v, "hub"))
+            G.plan = SPMV_HIP_PLAN_HUB;
         else if (strcmp(v, "auto"))
-            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped|blocked", v);
+            die("SPMV_HIP_PLAN=%s: expected auto|ordered|stream|vector[:L]|binned|tiled|striped|blocked|hub", v);
     }
     G.dispatch = DISPATCH_AUTO;
     if ((v = getenv("SPMV_HIP_DISPATCH"))) {

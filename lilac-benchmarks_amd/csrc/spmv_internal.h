@@ -261,6 +261,47 @@ int spmv_blocked_build_device(const int *d_rowptr, const int *d_col, const void 
 void spmv_blocked_free(spmv_dev_blocked *d);
 int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *stream);
 
+/* HUB (spmv_hub.hip): the CSR stream as it lies -- values untouched -- read in fixed chunks by persistent workgroups that
+ * keep the most referenced ("hub") columns of x in LDS; a remapped copy of the column indices says per entry hub slot or
+ * column, and where a row ends.  For power-law graphs, where a few thousand columns take most of the gathers. */
+#define SPMV_HUB_CHUNK 1024        /* entries per chunk (a wave's unit of work)                                  */
+#define SPMV_HUB_WAVES 16          /* waves per workgroup: one workgroup per CU                                  */
+#define SPMV_HUB_FLAG_HUB 0x80000000u /* col2: bits 0.. = slot of the LDS table, else the 0-based column          */
+#define SPMV_HUB_FLAG_END 0x40000000u /* col2: the entry is the last of its row                                   */
+typedef struct spmv_hub_plan {
+    int K;            /* hub columns chosen (<= spmv_hub_lds_slots)                                               */
+    int64_t covered;  /* entries whose column is a hub                                                             */
+    int CH, n_chunks; /* entries per chunk, chunks                                                                 */
+    int n_nzrows, n_empty, n_fix, identity;
+    int *hubcol;      /* [K] 0-based columns, ascending                                                            */
+    int *slot_of;     /* [cols] slot or -1                                                                         */
+    int *rank0;       /* [n_chunks + 1]                                                                            */
+    int *nzrow;       /* [n_nzrows]                                                                                */
+    int *erow;        /* [n_empty]                                                                                 */
+    int *fix;         /* [n_fix * 3] row, first chunk, chunk of the row's end                                      */
+} spmv_hub_plan;
+int spmv_hub_lds_slots(int elem_size);
+int spmv_hub_select(const int *colcount, int cols, int kmax, int min_count, spmv_hub_plan *g);
+int spmv_hub_rows(const int *rowptr, int base, int rows, int ch, spmv_hub_plan *g);
+void spmv_hub_plan_free(spmv_hub_plan *g);
+typedef struct spmv_dev_hub {
+    unsigned int *col2; /* [nnz + SPMV_PAD_ELEMS] remapped columns with flags; the pads point to the table's zero      */
+    int *hubcol;        /* [K]                                                                                        */
+    void *xh;           /* T[slots + 16]: the packed hub entries of x, rewritten by every product                     */
+    int *rank0, *nzrow, *erow, *fix;
+    void *carry;        /* T[n_chunks]: scratch, rewritten by every product                                           */
+    const void *val;    /* the CSR copy's values (not owned)                                                          */
+    int elem, rows, cols, K, slots, CH, n_chunks, n_nzrows, n_empty, n_fix, identity, n_wg;
+    int64_t nnz, covered;
+    size_t bytes;
+} spmv_dev_hub;
+/* rowptr_host: the block's row pointers on the host, rowptr_host[0] = their base.  0; -2 not suited (auto_choice: too few entries hit a hub) or
+ * not representable (2^30 columns or more); -3 out of memory; -1 a HIP error */
+int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host, const int *d_col, const void *d_val, int rows, int cols,
+                          int elem_size, int64_t nnz, int auto_choice, void *stream, spmv_dev_hub *out);
+void spmv_hub_free(spmv_dev_hub *d);
+int spmvk_hub(const spmv_dev_hub *d, const void *x, void *y, void *stream);
+
 struct spmv_hip_matrix;
 /* y = A x plus block partials of y . v when the plan can fold them in (STRIPED): returns the number
  * of partials (one per wave range when a workgroup walks every stripe, else one per 256 rows; <= rows + 16), 0 = not folded (run a separate dot), -1 = error */

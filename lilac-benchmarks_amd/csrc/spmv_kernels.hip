@@ -162,7 +162,9 @@ __global__ void __launch_bounds__(SPMV_WG) k_vector(const int *__restrict__ rowp
 /* ================================ k_stream ====================================== */
 /* DIAG: the debug build's timing-only twin (tuning key 6; results are wrong when a bit is set): 1 = no phase 2 (what do
  * the loads, the gathers and the LDS parking cost alone), 2 = every gather goes to the first KiB of x (what do the
- * gather MISSES cost), 4 = no row pointers either.  The shipped instantiation (DIAG = false) contains none of it. */
+ * gather MISSES cost), 4 = no row pointers either, 8 = the gathers of R-MAT's popular columns -- those whose 0-based index has
+ * at most (mask >> 8) bits set -- go to the first KiB (what would an LDS-resident table of the hub columns leave).  The
+ * shipped instantiation (DIAG = false) contains none of it. */
 template <typename T, bool NT, bool DIAG>
 __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
                                                     const int *__restrict__ rowptr,
@@ -218,7 +220,8 @@ __global__ void __launch_bounds__(SPMV_WG) k_stream(const int *__restrict__ blk,
     for (int k = 0; k < ROUNDS; ++k)
 #pragma unroll
         for (int i = 0; i < E; ++i)
-            xg[k][i] = xm1[(abl & 2) ? 1 + (c[k][i] & 127) : c[k][i]];
+            xg[k][i] = xm1[((abl & 2) || ((abl & 8) && __builtin_popcount((unsigned)c[k][i] - 1u) <= (abl >> 8))) ? 1 + (c[k][i] & 127)
+                                                                                                                    : c[k][i]];
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k) {
         VT p;

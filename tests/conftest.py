@@ -46,7 +46,7 @@ def build_planlib():
     return out
 
 
-PLAN_SOURCES = ("spmv_plan.c", "spmv_striped.c", "spmv_tiled.c", "spmv_blocked_plan.c")
+PLAN_SOURCES = ("spmv_plan.c", "spmv_striped.c", "spmv_tiled.c", "spmv_blocked_plan.c", "spmv_hub_plan.c")
 
 
 @pytest.fixture(scope="session")

@@ -24,13 +24,21 @@ D per plan (csrc/spmv_kernels.hip):
                 spans k sub-windows carries k - 1 times more; then one add per further stripe of the group the row has
                 entries in and one per further group -- at most min(n, stripes) each (exact zeros do not count):
                 D = 15 + ceil(n / 256) + 2 min(n, stripes).  Bar: (n + 16 + ceil(n/256) + 2 min(n, stripes)) u S.
+  BLOCKED       a row's products are added to its sum in LDS in stream order (with RUNS: a run is summed first, <= 4 lane-local
+                adds and the scan's 6 steps), a cut bin's slots in slot order: D <= n + 10: the CSR bar covers it.
+  HUB           (csrc/spmv_hub.hip) per sub-step of 64 lanes x E entries (E = 2 doubles / 4 floats): up to E lane-local adds,
+                6 steps of the segmented wave scan, 1 carry from the previous sub-step, up to E more adds of the lane that
+                closes the row: 2 E + 7 <= 15; a row that spans k sub-steps carries k - 1 times more; a row that crosses
+                chunks of 1024 entries adds its chunks' carries lane-strided (ceil(chunks / 64) adds), a 6-step tree, and
+                the piece in its last chunk: D = 22 + ceil(n / 128) + ceil(n / 65536).
+                Bar: (n + 23 + ceil(n/128) + ceil(n/65536)) u S.
 Second-order terms ((n u)^2 S) are covered by the factor 1.01.  When the plan is not known (the ABI's automatic choice)
 the larger of the two bars applies.  Round 2 used (n + 24) u S, a constant chosen to cover the shapes tested; for the NPB
 shapes the derived STRIPED bar is within a few per cent of it (class C: n = 241, 10 stripes: 278 against 265).
 """
 import numpy as np
 
-STRIPED, CSR = "striped", "csr"
+STRIPED, CSR, HUB = "striped", "csr", "hub"
 
 
 def row_tolerance(lens, absum, eps, plan=None, stripes=128):
@@ -41,7 +49,9 @@ def row_tolerance(lens, absum, eps, plan=None, stripes=128):
     n = np.asarray(lens, dtype=np.float64)
     csr = 2.0 * n + 6.0
     striped = n + 16.0 + np.ceil(n / 256.0) + 2.0 * np.minimum(n, float(stripes))
-    if plan == STRIPED:
+    if plan == HUB:
+        k = n + 23.0 + np.ceil(n / 128.0) + np.ceil(n / 65536.0)
+    elif plan == STRIPED:
         k = striped
     elif plan == CSR:
         k = csr

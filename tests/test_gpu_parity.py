@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 import matgen
-from rowtol import CSR, STRIPED, row_tolerance
+from rowtol import CSR, HUB, STRIPED, row_tolerance
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -66,7 +66,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
             try:
                 m.set_plan(plan, param)
             except RuntimeError as e:
-                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED, pkg.PLAN_BLOCKED) and "not representable" in str(e):
+                if plan in (pkg.PLAN_TILED, pkg.PLAN_STRIPED, pkg.PLAN_BLOCKED, pkg.PLAN_HUB) and "not representable" in str(e):
                     skipped.append(plan)  # a chunk above 65535 entries, mostly filler: AUTO falls back to STREAM for such matrices
                     continue
                 raise
@@ -78,6 +78,8 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
                 i2 = m.info()  # the plan in use (AUTO has chosen by now) decides which bar applies
                 if i2["plan"] == pkg.PLAN_STRIPED:
                     assert_close_rows(y, y_ref, absum, lens, a.dtype, tag, STRIPED, -(-max(i2["cols"], 1) // max(i2["plan_param"], 1)))
+                elif i2["plan"] == pkg.PLAN_HUB:
+                    assert_close_rows(y, y_ref, absum, lens, a.dtype, tag, HUB)
                 else:
                     assert_close_rows(y, y_ref, absum, lens, a.dtype, tag, CSR)
     finally:
@@ -87,7 +89,7 @@ def check_matrix_plans(pkg, backend, oracle, rs, ci, a, x, plans, what):
 
 def all_plans(pkg):
     P = [(pkg.PLAN_ORDERED, 0), (pkg.PLAN_STREAM, 0), (pkg.PLAN_BINNED, 0), (pkg.PLAN_AUTO, 0), (pkg.PLAN_TILED, 0), (pkg.PLAN_STRIPED, 0),
-         (pkg.PLAN_BLOCKED, 0)]
+         (pkg.PLAN_BLOCKED, 0), (pkg.PLAN_HUB, 0)]
     P += [(pkg.PLAN_VECTOR, l) for l in (1, 2, 4, 8, 16, 32, 64)]
     return P
 
@@ -1331,6 +1333,47 @@ def test_striped_is_bit_identical_to_its_documented_order(pkg, backend, planlib,
                 name, neq.size, rows, neq[0], got[neq[0]], want[neq[0]])
         finally:
             m.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hub_is_bit_identical_to_its_documented_order(pkg, backend, planlib, oracle, dtype):
+    """HUB (csrc/spmv_hub.hip) adds a row's products in an order fixed by the plan alone -- chunks of 1024 entries, sub-steps
+    of 64 lanes, a segmented wave scan, the carries of a row that crosses chunks in chunk order -- with no atomics on values
+    and no contraction, whichever wave draws which chunk: the GPU's bits equal tests/hub_order.py's restatement, on graphs
+    with hub rows that span dozens of chunks, on matrices with many empty rows, with rows that end exactly on chunk
+    boundaries; repetitions and a second build give the same bits again."""
+    import hub_order
+    rng = np.random.default_rng(77)
+    cases = {
+        "rmat_16": matgen.rmat_graph(41, 16, 16, dtype, values="normal"),
+        "rmat_17_f": matgen.rmat_graph(42, 17, 8, dtype, values="normal"),
+        "chunk_exact": matgen.csr_from_lengths(rng, [1024, 512, 512, 1, 1023, 2048, 1, 0, 0, 4096 * 3 + 5, 7], 9000, dtype),
+        "many_empty": matgen.csr_from_lengths(rng, np.where(rng.random(40000) < 0.8, 0, 9), 30000, dtype),
+        "npb_like": matgen.npb_like(43, 3000, 150, dtype),
+        "long_rows_mixed": matgen.edge_cases(dtype)["long_rows_mixed"][:3],
+    }
+    for name, (rs, ci, a) in cases.items():
+        rows, cols = rs.size - 1, int(ci.max())
+        x = rng.standard_normal(cols).astype(dtype)
+        p = hub_order.plan(planlib, rs, ci, cols, hub_order.lds_slots(planlib, dtype))
+        want = hub_order.product(p, rs, ci, a, x)
+        got = []
+        for build in range(2):
+            m = backend.matrix(a, rs, ci, rows)
+            try:
+                m.set_plan(pkg.PLAN_HUB, 0)
+                inf = m.info()
+                assert inf["plan"] == pkg.PLAN_HUB and inf["plan_param"] == p["K"], (name, inf, p["K"])
+                assert inf["n_launches"] == 1 + (p["K"] > 0) + (len(p["fix"]) > 0 or len(p["erow"]) > 0), (name, inf)
+                for _ in range(3):
+                    got.append(m.spmv_host(x))
+            finally:
+                m.close()
+        for y in got:
+            assert np.array_equal(bits(y), bits(want)), "%s: %d rows differ from the documented order" % (
+                name, int(np.count_nonzero(bits(y) != bits(want))))
+        y_ref = oracle.spmv(a, x, rs, ci, rows)
+        assert_close_rows(got[0], y_ref, oracle.absum(a, x, rs, ci, rows), np.diff(rs), dtype, name, HUB)
 
 
 def test_blocked_plan(pkg, backend, oracle):

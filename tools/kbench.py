@@ -91,7 +91,7 @@ def main():
     be.set_tuning(12, args.swrows)
     groups = [int(v) for v in args.sgroups.split(",")]
     be.set_tuning(11, groups[0])
-    plans = [("striped", pkg.PLAN_STRIPED, 0), ("blocked", pkg.PLAN_BLOCKED, 0), ("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
+    plans = [("striped", pkg.PLAN_STRIPED, 0), ("blocked", pkg.PLAN_BLOCKED, 0), ("hub", pkg.PLAN_HUB, 0), ("tiled", pkg.PLAN_TILED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec64", pkg.PLAN_VECTOR, 64), ("vec32", pkg.PLAN_VECTOR, 32),
              ("vec16", pkg.PLAN_VECTOR, 16), ("vec8", pkg.PLAN_VECTOR, 8), ("vec4", pkg.PLAN_VECTOR, 4),
              ("vec1", pkg.PLAN_VECTOR, 1), ("binned", pkg.PLAN_BINNED, 0), ("ordered", pkg.PLAN_ORDERED, 0),
              ("auto", pkg.PLAN_AUTO, 0)]
