@@ -439,10 +439,11 @@ static void print_stats(void)
     const spmv_hip_stats *s = &G.st;
     fprintf(stderr,
             "libhip-spmv: calls=%lld (host %lld) uploads=%lld value_refreshes=%lld invalidations=%lld init=%.3fs upload=%.3fs "
-            "x_h2d=%.3fs kernel=%.3fs y_d2h=%.3fs host=%.3fs total=%.3fs\n",
+            "x_h2d=%.3fs kernel=%.3fs y_d2h=%.3fs host=%.3fs total=%.3fs pinned_in_place=%d\n",
             (long long)s->calls, (long long)s->host_calls, (long long)s->uploads, (long long)s->value_refreshes,
             (long long)s->invalidations,
-            s->t_init, s->t_upload, s->t_x_h2d, s->t_kernel, s->t_y_d2h, s->t_host, s->t_total);
+            s->t_init, s->t_upload, s->t_x_h2d, s->t_kernel, s->t_y_d2h, s->t_host, s->t_total,
+            G.nreg /* caller vectors pinned where they lie: static storage (COMMON blocks, C globals) or SPMV_HIP_PIN=register */);
 }
 
 void spmv_hip_release(void)

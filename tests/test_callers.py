@@ -290,3 +290,23 @@ def test_pathsample_counterpart_on_the_oracle(pkg, oracle, reference):
     once = C.ps_committor(net, oracle.harness_fn(), 1, 1)["gpfold"]
     assert np.array_equal(res[1], once)  # NGT: every call computes the same product
     C.ps_free(net)
+
+
+def _f_kat(name):
+    exe = os.path.join(os.path.dirname(__file__), "native", "_build", name)
+    if not os.path.exists(exe):
+        pytest.skip("tests/native/_build/%s was not built (no amdflang, or no reference build, when build() ran)" % name)
+    return exe
+
+
+def test_fortran_caller_on_the_references_native_library(reference):
+    """tests/native/f_kat.f -- the call of NPB's cg.f:532 on COMMON-block vectors (cg.f:69-80) -- linked the way the
+    reference's callers link (-lnative-spmv) and run on the reference's own native.so: the stub itself is right (its
+    Fortran restatement of native-impl.c:1-12 agrees with the C one to the last bit: worst difference 0)."""
+    import re
+    import subprocess
+    exe = _f_kat("f_kat_native")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(os.path.dirname(exe), "refnative"))
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "f_kat: success" in r.stdout, r.stdout + r.stderr
+    assert re.search(r"rows beyond the bound =\s+0 worst \|dq\| / sum\|a p\| =\s+0\.00E\+00", r.stdout), r.stdout

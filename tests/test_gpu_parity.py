@@ -1799,3 +1799,47 @@ def test_the_references_parboil_program_runs_on_the_library(pkg, tmp_path, datas
     assert a.size == b.size and np.array_equal(a[:4], b[:4])
     assert pkg.callers.pb_compare(b[4:].view(np.float32), a[4:].view(np.float32)) == 0
     assert "libhip-spmv: calls=50 (host 0) uploads=1" in r.stderr
+
+
+# ------------------------------------------------------------------ a Fortran object calls the library
+def _f_kat_line(out):
+    m = re.search(r"20 alternating products, \|p\|\^2 =\s*([0-9.E+-]+)", out)
+    assert m, out
+    return float(m.group(1))
+
+
+@pytest.mark.parametrize("route", ["lhip-spmv", "installed-as-libnative-spmv"])
+def test_a_fortran_caller_with_common_block_vectors(pkg, tmp_path, route):
+    """tests/native/f_kat.f compiled by amdflang (tests/native/Makefile, run by build()): `call spmv_harness(q, a, p,
+    rowstr, colidx, rows)` exactly as /root/reference/NPB3.3.1/CG/cg.f:532 does, with a, colidx, rowstr, p, q in COMMON
+    (cg.f:69-80).  Two link routes of INTEGRATION.md section 2: the `ifeq` arm (-lhip-spmv), and the zero-edit one -- a
+    binary linked against libnative-spmv.so finds libhip-spmv.so under that name first on LD_LIBRARY_PATH.  The stub
+    checks test.cpp's 12 x 12 known answer and a class-S-sized product per row itself; here: every product ran on the
+    GPU, the matrix was uploaded twice (the stub rewrites the COMMON arrays between part 1 and 2: same pointers, new
+    contents), the COMMON vectors p and q were pinned where they lie (has_static_storage, spmv_harness.c), and the
+    power iteration's |p|^2 equals the reference library's to 1e-10 (the bar of cg.f:363-368)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bdir = os.path.join(root, "tests", "native", "_build")
+    env = dict(os.environ, SPMV_HIP_STATS="1", SPMV_HIP_DISPATCH="device")
+    if route == "lhip-spmv":
+        exe = os.path.join(bdir, "f_kat_hip")
+    else:
+        exe = os.path.join(bdir, "f_kat_native")
+        import shutil
+        shutil.copy(pkg.lib_path(), str(tmp_path / "libnative-spmv.so"))
+        env["LD_LIBRARY_PATH"] = str(tmp_path) + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    assert os.path.exists(exe), "%s missing: __graft_entry__.build() compiles it with amdflang (tests/native/Makefile)" % exe
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "f_kat: success" in r.stdout, r.stdout + r.stderr[-2000:]
+    m = re.search(r"libhip-spmv: calls=(\d+) \(host (\d+)\) uploads=(\d+) .* pinned_in_place=(\d+)", r.stderr)
+    assert m, r.stderr[-800:]
+    calls, host, uploads, pinned = (int(v) for v in m.groups())
+    assert (calls, host, uploads) == (22, 0, 2) and pinned >= 2, r.stderr[-800:]
+    ref_exe = os.path.join(bdir, "f_kat_native")
+    ref_dir = os.path.join(bdir, "refnative")
+    if os.path.exists(os.path.join(ref_dir, "libnative-spmv.so")):  # the reference's own native.so (built artefact, travels)
+        rr = subprocess.run([ref_exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120,
+                            env=dict(os.environ, LD_LIBRARY_PATH=ref_dir))
+        assert rr.returncode == 0, rr.stdout + rr.stderr
+        a, b = _f_kat_line(r.stdout), _f_kat_line(rr.stdout)
+        assert abs(a - b) <= 1e-10 * abs(b), (a, b)
