@@ -33,6 +33,8 @@
 extern "C" void spmvk_set_tuning(int key, int value);
 extern "C" void spmvk_blocked_set_bin_rows(int per_xcd);
 extern "C" void spmvk_hub_set_min_cover(int per_cent);
+extern "C" void spmvk_hub_set_table_bytes(int bytes);
+extern "C" void spmvk_hub_set_lds_cap(int columns);
 extern "C" int spmvk_get_tuning_xcd(void);
 static bool g_tune_xcd_enabled() { return spmvk_get_tuning_xcd() != 0; }
 
@@ -753,7 +755,7 @@ static int ensure_hub(spmv_hip_matrix *m, bool auto_choice)
     }
     m->hub_rc = rc;
     if (rc == -2)
-        spmv_set_error("matrix not representable in the HUB layout (2^30 columns or more) or not suited to it (too few entries in hub columns)");
+        spmv_set_error("matrix not representable in the HUB layout (2^29 columns or more) or not suited to it (too few entries in hub columns)");
     else if (rc == -3)
         spmv_set_error("out of memory for the HUB layout");
     if (rc)
@@ -768,7 +770,7 @@ static int ensure_hub(spmv_hip_matrix *m, bool auto_choice)
  * builder counts the references per column and declines when they do not. */
 static bool hub_nominated(const spmv_hip_matrix *m)
 {
-    return m->nnz >= 2000000 && (int64_t)m->cols * m->elem >= (2ll << 20) && m->cols < (1 << 30);
+    return m->nnz >= 2000000 && (int64_t)m->cols * m->elem >= (2ll << 20) && m->cols < (1 << 29);
 }
 
 spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const int *colidx, int rows,
@@ -1093,7 +1095,7 @@ static int n_launches(const spmv_hip_matrix *m)
     case SPMV_HIP_PLAN_STRIPED: return m->ds.NG > 1 ? 2 : 1;
     case SPMV_HIP_PLAN_BLOCKED: return m->db.n_join > 0 ? 3 : 2; /* + k_blk_join when a bin was cut */
     case SPMV_HIP_PLAN_STREAM: return 1 + longk;
-    case SPMV_HIP_PLAN_HUB: return 1 + (m->dh.K > 0) + (m->dh.n_fix > 0 || m->dh.n_empty > 0); /* k_hub_pack, k_hub, k_hub_fix */
+    case SPMV_HIP_PLAN_HUB: return 1 + (m->dh.K + m->dh.K2 > 0) + (m->dh.n_fix > 0 || m->dh.n_empty > 0); /* k_hub_pack, k_hub, k_hub_fix */
     case SPMV_HIP_PLAN_BINNED: {
         int n = longk;
         for (int b = 0; b < SPMV_NBINS; ++b)
@@ -1518,6 +1520,10 @@ void spmv_hip_set_tuning(int key, int value)
         spmvk_blocked_set_bin_rows(value); /* BLOCKED: rows per bin of layouts built from now on */
     else if (key == 21)
         spmvk_hub_set_min_cover(value); /* HUB: per cent of the entries that must hit a hub column for AUTO to keep the plan */
+    else if (key == 23)
+        spmvk_hub_set_lds_cap(value); /* HUB: at most this many columns in the LDS table of layouts built from now on (< 0: what fits) */
+    else if (key == 22)
+        spmvk_hub_set_table_bytes(value); /* HUB: bytes of the dense second-tier table in memory of layouts built from now on (0: none) */
     else if (key == 17 && value >= 0 && value <= 2)
         g_striped_builder = value; /* 0: the device builds the STRIPED layout (the host when it must), 1: host, 2: device or fail */
     else if (key == 15 && value >= 0 && value <= 2)

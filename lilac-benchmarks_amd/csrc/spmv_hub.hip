@@ -12,8 +12,12 @@
  * The plan:
  *   - the matrix stays where it is: values are read from the CSR copy (a value refresh costs this plan nothing); a second
  *     copy of the COLUMN INDICES (col2, 4 bytes per entry, read instead of the original) says per entry: hub -> the slot of an
- *     LDS table, otherwise the 0-based column; bit 30 marks the last entry of a row;
- *   - k_hub_pack gathers the hub entries of x into a dense table (one small launch);
+ *     LDS table (bit 31), otherwise the 0-based column; bit 30 marks the last entry of a row;
+ *   - a second tier behind the LDS table (round 4, profiles/r04_hub_table_by_size.log): the next 256 K most referenced columns
+ *     get slots of a dense 2-MB table in memory (col2 bit 29).  A gather that misses the cache moves a 128-byte line for
+ *     8 bytes; the hot columns of a power-law graph are scattered one to a line over all of x, packed they are lines that every
+ *     XCD's L2 keeps.  R-MAT 2^22 (x = 32 MB): 520 -> 390 us; 2^20 (x = 8 MB, half of it per L2 anyway): 72 -> 70;
+ *   - k_hub_pack gathers the hub entries of x into the dense tables (one small launch);
  *   - k_hub: one persistent workgroup of 16 waves per CU copies the table into LDS (128 KB) and takes a contiguous range of
  *     CHUNKS of the entry stream -- 1024 entries each, whatever the rows: no row blocks, no long-row kernels, every wave
  *     the same amount of work; its waves draw chunks from an LDS ticket.  Per sub-step of 64 x 16 bytes a wave multiplies
@@ -35,7 +39,7 @@
 
 namespace {
 
-constexpr unsigned int HUB = SPMV_HUB_FLAG_HUB, END = SPMV_HUB_FLAG_END, IDX = 0x3fffffffu;
+constexpr unsigned int HUB = SPMV_HUB_FLAG_HUB, END = SPMV_HUB_FLAG_END, TBL = SPMV_HUB_FLAG_TBL, IDX = 0x1fffffffu;
 constexpr int WAVES = SPMV_HUB_WAVES, NT_WG = WAVES * 64, CH = SPMV_HUB_CHUNK;
 
 template <typename T> struct HubGeom {
@@ -140,8 +144,8 @@ __global__ void __launch_bounds__(NT_WG) k_hub(const unsigned int *__restrict__ 
             for (int i = 0; i < E; ++i) {
                 const unsigned int cc = (unsigned int)cur.c[k][i];
                 xv[k][i] = (T)0;
-                if (!(cc & HUB))
-                    xv[k][i] = x[cc & IDX];
+                if (!(cc & HUB)) /* tier 1: the dense table in memory (cache hits); else x itself */
+                    xv[k][i] = ((cc & TBL) ? xh : x)[cc & IDX];
             }
         /* ---- the next stage's stream loads: no branch around them (past the end: this chunk again, never used) ---- */
         int nc = c, nst = st + 1;
@@ -270,11 +274,13 @@ __global__ void __launch_bounds__(256) k_hub_fix(const int *__restrict__ fix, in
 #pragma clang fp contract(fast)
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_hub_pack(const int *__restrict__ hubcol, int K, const T *__restrict__ x, T *__restrict__ xh)
+__global__ void __launch_bounds__(256) k_hub_pack(const int *__restrict__ hubcol, int n, const T *__restrict__ x, T *__restrict__ xh)
 {
     const int s = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (s < K)
-        xh[s] = x[hubcol[s]];
+    if (s < n) {
+        const int c = hubcol[s]; /* -1: the zero behind tier 0 and the pads up to tier 1 */
+        xh[s] = c >= 0 ? x[c] : (T)0;
+    }
 }
 
 /* ---------------------------------------------------------------- the builder */
@@ -285,14 +291,14 @@ __global__ void __launch_bounds__(256) k_hub_hist(const int *__restrict__ col, l
 }
 
 __global__ void __launch_bounds__(256) k_hub_remap(const int *__restrict__ col, long long nnz, long long n_alloc,
-                                                   const int *__restrict__ slot_of, unsigned int zero_slot,
+                                                   const int *__restrict__ slot_of, unsigned int zero_slot, int K, int base1,
                                                    unsigned int *__restrict__ col2)
 {
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n_alloc; j += (long long)gridDim.x * 256) {
         unsigned int v = HUB | zero_slot; /* the pads: 0 (the CSR copy's value pad) x 0 (the table's zero) */
         if (j < nnz) {
             const int c = col[j] - 1, s = slot_of[c];
-            v = s >= 0 ? (HUB | (unsigned int)s) : (unsigned int)c;
+            v = s < 0 ? (unsigned int)c : s < K ? (HUB | (unsigned int)s) : (TBL | (unsigned int)(base1 + s - K));
         }
         col2[j] = v;
     }
@@ -306,6 +312,9 @@ __global__ void __launch_bounds__(256) k_hub_ends(const int *__restrict__ rowptr
 }
 
 std::atomic<int> g_hub_min_cover{25}; /* per cent of the entries that must hit a hub for the automatic choice to keep the plan */
+std::atomic<int> g_hub_table_bytes{SPMV_HUB_TABLE_BYTES}; /* tier 1: bytes of the dense table in memory (0: none) */
+std::atomic<int> g_hub_lds_cap{1 << 30};                  /* tier 0: at most this many columns in the LDS table (tests: small, so
+                                                             that small matrices reach tier 1 and x itself) */
 int g_hub_cus = 0;
 
 } // namespace
@@ -335,18 +344,31 @@ extern "C" void spmvk_hub_set_min_cover(int per_cent)
         g_hub_min_cover.store(per_cent, std::memory_order_relaxed);
 }
 
+extern "C" void spmvk_hub_set_lds_cap(int columns)
+{
+    g_hub_lds_cap.store(columns >= 0 ? columns : 1 << 30, std::memory_order_relaxed);
+}
+
+extern "C" void spmvk_hub_set_table_bytes(int bytes)
+{
+    if (bytes >= 0 && bytes <= (256 << 20))
+        g_hub_table_bytes.store(bytes, std::memory_order_relaxed);
+}
+
 extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host, const int *d_col, const void *d_val, int rows,
                                      int cols, int elem_size, int64_t nnz, int auto_choice, void *stream, spmv_dev_hub *out)
 {
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     memset(out, 0, sizeof *out);
-    if (rows <= 0 || cols <= 0 || nnz <= 0 || nnz > 0x7fffffffll - 2 * SPMV_PAD_ELEMS || cols >= (1 << 30) || !rowptr_host)
+    if (rows <= 0 || cols <= 0 || nnz <= 0 || nnz > 0x7fffffffll - 2 * SPMV_PAD_ELEMS || cols >= (1 << 29) || !rowptr_host)
         return -2;
     const int slots = spmv_hub_lds_slots(elem_size);
     const size_t n_alloc = (size_t)nnz + SPMV_PAD_ELEMS;
     const unsigned int grid = nnz < 256ll * 8192 ? (unsigned int)((nnz + 255) / 256) : 8192u;
-    int *d_cnt = nullptr, *h_cnt = nullptr, *d_slot = nullptr;
+    int *d_cnt = nullptr, *h_cnt = nullptr, *d_slot = nullptr, *h_hubcol = nullptr;
+    int base1 = 0;
+    size_t n_slots = 0;
     spmv_hub_plan g;
     spmv_dev_hub d;
     memset(&g, 0, sizeof g);
@@ -364,10 +386,15 @@ extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host
     HBCHK(hipMemcpyAsync(h_cnt, d_cnt, (size_t)cols * sizeof(int), hipMemcpyDeviceToHost, st));
     HBCHK(hipStreamSynchronize(st));
     /* ---- the decisions (spmv_hub_plan.c) */
-    rc = spmv_hub_select(h_cnt, cols, slots, 2, &g);
+    {
+        const int cap = g_hub_lds_cap.load(std::memory_order_relaxed);
+        rc = spmv_hub_select(h_cnt, cols, cap < slots ? cap : slots, g_hub_table_bytes.load(std::memory_order_relaxed) / elem_size, 2, &g);
+    }
     if (rc)
         goto out;
-    if (auto_choice && 100 * g.covered < (int64_t)g_hub_min_cover.load(std::memory_order_relaxed) * nnz) {
+    base1 = (g.K + 1 + 15) / 16 * 16; /* tier 1 begins on a 64- / 128-byte boundary behind tier 0 and its zero */
+    n_slots = (size_t)base1 + (size_t)g.K2;
+    if (auto_choice && 100 * (g.covered + g.covered2) < (int64_t)g_hub_min_cover.load(std::memory_order_relaxed) * nnz) {
         rc = -2; /* no hubs to speak of: the CSR kernel gathers as well */
         goto out;
     }
@@ -379,16 +406,25 @@ extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host
     HBCHK(hipMemcpyAsync(d_slot, g.slot_of, (size_t)cols * sizeof(int), hipMemcpyHostToDevice, st));
     HBCHK(hipMalloc((void **)&d.col2, n_alloc * sizeof(unsigned int)));
     hipLaunchKernelGGL(k_hub_remap, dim3(grid), dim3(256), 0, st, d_col, (long long)nnz, (long long)n_alloc, d_slot,
-                       (unsigned int)g.K, d.col2);
+                       (unsigned int)g.K, g.K, base1, d.col2);
     HBCHK(hipGetLastError());
     hipLaunchKernelGGL(k_hub_ends, dim3((unsigned int)((rows + 255) / 256)), dim3(256), 0, st, d_rowptr, rows, d.col2);
     HBCHK(hipGetLastError());
     /* ---- the small arrays */
-    HBCHK(hipMalloc((void **)&d.hubcol, ((size_t)g.K + 1) * sizeof(int)));
-    if (g.K)
-        HBCHK(hipMemcpyAsync(d.hubcol, g.hubcol, (size_t)g.K * sizeof(int), hipMemcpyHostToDevice, st));
-    HBCHK(hipMalloc(&d.xh, ((size_t)slots + 16) * (size_t)elem_size));
-    HBCHK(hipMemsetAsync(d.xh, 0, ((size_t)slots + 16) * (size_t)elem_size, st)); /* xh[K ..] = 0 for good: k_hub_pack writes [0, K) */
+    /* the column behind every slot of xh: tier 0, -1 (the zero and the pads), tier 1 */
+    h_hubcol = (int *)malloc((n_slots + 1) * sizeof(int));
+    if (!h_hubcol) {
+        rc = -3;
+        goto out;
+    }
+    for (int s = 0; s < base1; ++s)
+        h_hubcol[s] = s < g.K ? g.hubcol[s] : -1;
+    if (g.K2)
+        memcpy(h_hubcol + base1, g.hubcol + g.K, (size_t)g.K2 * sizeof(int));
+    HBCHK(hipMalloc((void **)&d.hubcol, (n_slots + 1) * sizeof(int)));
+    HBCHK(hipMemcpyAsync(d.hubcol, h_hubcol, n_slots * sizeof(int), hipMemcpyHostToDevice, st));
+    HBCHK(hipMalloc(&d.xh, (n_slots + 16) * (size_t)elem_size));
+    HBCHK(hipMemsetAsync(d.xh, 0, (n_slots + 16) * (size_t)elem_size, st));
     HBCHK(hipMalloc((void **)&d.rank0, ((size_t)g.n_chunks + 1) * sizeof(int)));
     HBCHK(hipMemcpyAsync(d.rank0, g.rank0, ((size_t)g.n_chunks + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     {
@@ -414,7 +450,8 @@ extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host
         g_hub_cus = cus;
     }
     d.val = d_val;
-    d.elem = elem_size, d.rows = rows, d.cols = cols, d.K = g.K, d.slots = slots, d.CH = CH, d.n_chunks = g.n_chunks;
+    d.elem = elem_size, d.rows = rows, d.cols = cols, d.K = g.K, d.K2 = g.K2, d.base1 = base1, d.slots = slots, d.CH = CH;
+    d.n_chunks = g.n_chunks, d.covered2 = g.covered2;
     d.n_nzrows = g.n_nzrows, d.n_empty = g.n_empty, d.n_fix = g.n_fix, d.identity = g.identity;
     d.nnz = nnz, d.covered = g.covered;
     {
@@ -423,13 +460,13 @@ extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host
             nwg = g_hub_cus;
         d.n_wg = nwg < 1 ? 1 : nwg;
     }
-    d.bytes = n_alloc * 4 + ((size_t)g.K + 1) * 4 + ((size_t)slots + 16) * (size_t)elem_size + ((size_t)g.n_chunks + 1) * (4 + (size_t)elem_size) +
+    d.bytes = n_alloc * 4 + (n_slots + 1) * 4 + (n_slots + 16) * (size_t)elem_size + ((size_t)g.n_chunks + 1) * (4 + (size_t)elem_size) +
               ((size_t)g.n_nzrows + 2 * HubGeom<float>::RING + 64) * 4 + ((size_t)g.n_empty + 1) * 4 + ((size_t)g.n_fix * 3 + 1) * 4;
     *out = d;
     memset(&d, 0, sizeof d);
 out:
     (void)hipFree(d_cnt), (void)hipFree(d_slot);
-    free(h_cnt);
+    free(h_cnt), free(h_hubcol);
     spmv_hub_plan_free(&g);
     if (rc)
         spmv_hub_free(&d);
@@ -440,8 +477,9 @@ namespace {
 template <typename T> void launch_hub(const spmv_dev_hub *d, const void *x, void *y, hipStream_t st)
 {
     using G = HubGeom<T>;
-    if (d->K > 0)
-        hipLaunchKernelGGL(k_hub_pack<T>, dim3((unsigned int)((d->K + 255) / 256)), dim3(256), 0, st, d->hubcol, d->K, (const T *)x, (T *)d->xh);
+    const int n_slots = d->K2 > 0 ? d->base1 + d->K2 : d->K;
+    if (n_slots > 0)
+        hipLaunchKernelGGL(k_hub_pack<T>, dim3((unsigned int)((n_slots + 255) / 256)), dim3(256), 0, st, d->hubcol, n_slots, (const T *)x, (T *)d->xh);
     const int kpad = (d->K + 1 + G::E - 1) / G::E * G::E; /* the table and its zero, in 16-byte units */
     const int per = (d->n_wg + 7) / 8, grid = per * 8;
     if (d->identity)

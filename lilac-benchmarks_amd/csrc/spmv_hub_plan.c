@@ -1,6 +1,7 @@
 /*
  * csrc/spmv_hub_plan.c -- the host side of the HUB plan (spmv_hub.hip): every DECISION of the layout -- which columns of x
  * are hubs and get a slot of the LDS table, how the entry stream is cut into chunks, which row ends a chunk starts with,
+ * which further columns get a slot of the dense table in memory behind it,
  * which rows cross a chunk boundary and are finished by the second launch, which rows are empty -- from one count per
  * column (taken on the device) and the block's row pointers.  Plain C so that the CPU tests can walk the result and
  * restate the kernel's data flow on top of it (tests/test_hub_layout.py); the data movement is the .hip file's.
@@ -26,60 +27,97 @@ void spmv_hub_plan_free(spmv_hub_plan *g)
 int spmv_hub_lds_slots(int elem_size) { return elem_size == 8 ? 16352 : 32736; }
 
 /*
- * The hubs: the kmax columns referenced most often, ties to the lower column, none referenced fewer than min_count times
- * (a slot costs one gather when the table is packed: a column referenced once gains nothing).  hubcol ascending by column
- * (the pack kernel's gathers then walk x front to back), slot_of[c] = slot or -1.  covered = entries that hit a hub.
- * 0, or -3 without memory.
+ * Marks the kmax columns referenced most often among those with tier[c] == 0 -- ties to the lower column, none referenced
+ * fewer than min_count times -- with `mark`.  Returns how many, -3 without memory.
  */
-int spmv_hub_select(const int *colcount, int cols, int kmax, int min_count, spmv_hub_plan *g)
+static int64_t top_columns(const int *colcount, int cols, int64_t kmax, int min_count, unsigned char *tier, unsigned char mark)
 {
-    g->K = 0;
-    g->covered = 0;
-    g->hubcol = NULL;
-    g->slot_of = (int *)malloc((size_t)(cols > 0 ? cols : 1) * sizeof(int));
-    if (!g->slot_of)
-        return -3;
     int maxc = 0;
     for (int c = 0; c < cols; ++c)
-        if (colcount[c] > maxc)
+        if (!tier[c] && colcount[c] > maxc)
             maxc = colcount[c];
     /* how many columns have each count; from the top down until kmax are taken */
     int64_t *byc = (int64_t *)calloc((size_t)maxc + 2, sizeof(int64_t));
     if (!byc)
         return -3;
     for (int c = 0; c < cols; ++c)
-        byc[colcount[c]]++;
+        if (!tier[c])
+            byc[colcount[c]]++;
     if (min_count < 1)
         min_count = 1;
-    int t = maxc + 1; /* every column with count >= t is a hub */
+    int t = maxc + 1; /* every column with count >= t is taken */
     int64_t taken = 0;
     while (t - 1 >= min_count && taken + byc[t - 1] <= kmax) {
         --t;
         taken += byc[t];
     }
-    /* of the columns with count t - 1 the lowest ones fill the table */
-    int64_t partial = (t - 1 >= min_count) ? (int64_t)kmax - taken : 0;
+    /* of the columns with count t - 1 the lowest ones fill what is left */
+    int64_t partial = (t - 1 >= min_count) ? kmax - taken : 0;
     free(byc);
-    const int K = (int)(taken + partial);
-    g->hubcol = (int *)malloc((size_t)(K > 0 ? K : 1) * sizeof(int));
-    if (!g->hubcol)
-        return -3;
-    int k = 0;
+    int64_t k = 0;
     for (int c = 0; c < cols; ++c) {
-        int hub = colcount[c] >= t && colcount[c] >= min_count;
-        if (!hub && partial > 0 && colcount[c] == t - 1) {
-            hub = 1;
+        if (tier[c])
+            continue;
+        int take = colcount[c] >= t && colcount[c] >= min_count;
+        if (!take && partial > 0 && colcount[c] == t - 1) {
+            take = 1;
             --partial;
         }
-        if (hub) {
-            g->slot_of[c] = k;
-            g->hubcol[k++] = c;
+        if (take) {
+            tier[c] = mark;
+            ++k;
+        }
+    }
+    return k;
+}
+
+/*
+ * The hubs, in two tiers.  Tier 0: the kmax columns referenced most often, ties to the lower column, none referenced fewer
+ * than min_count times (a slot costs one gather when the table is packed: a column referenced once gains nothing) -- they
+ * get the slots [0, K) of the LDS table.  Tier 1: the kmax2 most referenced of the REST, same rule -- slots [K, K + K2) of a
+ * dense table in memory that the cache holds where it cannot hold the lines of x they are scattered over (one 128-byte line
+ * per column otherwise).  hubcol ascending by column within each tier (the pack kernel's gathers then walk x front to back),
+ * slot_of[c] = slot or -1.  covered / covered2 = entries that hit a tier-0 / tier-1 column.
+ * 0, or -3 without memory.
+ */
+int spmv_hub_select(const int *colcount, int cols, int kmax, int kmax2, int min_count, spmv_hub_plan *g)
+{
+    g->K = g->K2 = 0;
+    g->covered = g->covered2 = 0;
+    g->hubcol = NULL;
+    g->slot_of = (int *)malloc((size_t)(cols > 0 ? cols : 1) * sizeof(int));
+    unsigned char *tier = (unsigned char *)calloc((size_t)(cols > 0 ? cols : 1), 1);
+    if (!g->slot_of || !tier) {
+        free(tier);
+        return -3;
+    }
+    const int64_t K = top_columns(colcount, cols, kmax > 0 ? kmax : 0, min_count, tier, 1);
+    const int64_t K2 = K < 0 ? K : (kmax2 > 0 ? top_columns(colcount, cols, kmax2, min_count, tier, 2) : 0);
+    if (K < 0 || K2 < 0) {
+        free(tier);
+        return -3;
+    }
+    g->hubcol = (int *)malloc((size_t)(K + K2 > 0 ? K + K2 : 1) * sizeof(int));
+    if (!g->hubcol) {
+        free(tier);
+        return -3;
+    }
+    int k0 = 0, k1 = (int)K;
+    for (int c = 0; c < cols; ++c) {
+        if (tier[c] == 1) {
+            g->slot_of[c] = k0;
+            g->hubcol[k0++] = c;
             g->covered += colcount[c];
+        } else if (tier[c] == 2) {
+            g->slot_of[c] = k1;
+            g->hubcol[k1++] = c;
+            g->covered2 += colcount[c];
         } else {
             g->slot_of[c] = -1;
         }
     }
-    g->K = k;
+    g->K = (int)K, g->K2 = (int)K2;
+    free(tier);
     return 0;
 }
 

@@ -266,33 +266,38 @@ int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *strea
  * column, and where a row ends.  For power-law graphs, where a few thousand columns take most of the gathers. */
 #define SPMV_HUB_CHUNK 1024        /* entries per chunk (a wave's unit of work)                                  */
 #define SPMV_HUB_WAVES 16          /* waves per workgroup: one workgroup per CU                                  */
-#define SPMV_HUB_FLAG_HUB 0x80000000u /* col2: bits 0.. = slot of the LDS table, else the 0-based column          */
+#define SPMV_HUB_FLAG_HUB 0x80000000u /* col2: bits 0..28 = slot of the LDS table, else the 0-based column       */
 #define SPMV_HUB_FLAG_END 0x40000000u /* col2: the entry is the last of its row                                   */
+#define SPMV_HUB_FLAG_TBL 0x20000000u /* col2 (not HUB): bits 0..28 index the packed table in memory, not x       */
+#define SPMV_HUB_TABLE_BYTES (2 << 20) /* default size of that table: what an XCD's 4-MB L2 keeps next to the stream */
 typedef struct spmv_hub_plan {
-    int K;            /* hub columns chosen (<= spmv_hub_lds_slots)                                               */
-    int64_t covered;  /* entries whose column is a hub                                                             */
+    int K;            /* tier-0 hub columns: the LDS table (<= spmv_hub_lds_slots)                                */
+    int K2;           /* tier-1 hub columns: the dense table in memory                                            */
+    int64_t covered;  /* entries whose column is a tier-0 hub                                                      */
+    int64_t covered2; /* entries whose column is a tier-1 hub                                                      */
     int CH, n_chunks; /* entries per chunk, chunks                                                                 */
     int n_nzrows, n_empty, n_fix, identity;
-    int *hubcol;      /* [K] 0-based columns, ascending                                                            */
-    int *slot_of;     /* [cols] slot or -1                                                                         */
+    int *hubcol;      /* [K + K2] 0-based columns, ascending within each tier                                      */
+    int *slot_of;     /* [cols] slot ([0, K) tier 0, [K, K + K2) tier 1) or -1                                     */
     int *rank0;       /* [n_chunks + 1]                                                                            */
     int *nzrow;       /* [n_nzrows]                                                                                */
     int *erow;        /* [n_empty]                                                                                 */
     int *fix;         /* [n_fix * 3] row, first chunk, chunk of the row's end                                      */
 } spmv_hub_plan;
 int spmv_hub_lds_slots(int elem_size);
-int spmv_hub_select(const int *colcount, int cols, int kmax, int min_count, spmv_hub_plan *g);
+int spmv_hub_select(const int *colcount, int cols, int kmax, int kmax2, int min_count, spmv_hub_plan *g);
 int spmv_hub_rows(const int *rowptr, int base, int rows, int ch, spmv_hub_plan *g);
 void spmv_hub_plan_free(spmv_hub_plan *g);
 typedef struct spmv_dev_hub {
     unsigned int *col2; /* [nnz + SPMV_PAD_ELEMS] remapped columns with flags; the pads point to the table's zero      */
-    int *hubcol;        /* [K]                                                                                        */
-    void *xh;           /* T[slots + 16]: the packed hub entries of x, rewritten by every product                     */
+    int *hubcol;        /* [base1 + K2]: the column behind every slot of xh, -1 = none (xh stays 0 there)              */
+    void *xh;           /* T[base1 + K2 + 16]: the packed hub entries of x, rewritten by every product: [0, K) the LDS  */
+                        /* table, xh[K] = 0 (what the pads multiply with), [base1, base1 + K2) the table in memory     */
     int *rank0, *nzrow, *erow, *fix;
     void *carry;        /* T[n_chunks]: scratch, rewritten by every product                                           */
     const void *val;    /* the CSR copy's values (not owned)                                                          */
-    int elem, rows, cols, K, slots, CH, n_chunks, n_nzrows, n_empty, n_fix, identity, n_wg;
-    int64_t nnz, covered;
+    int elem, rows, cols, K, K2, base1, slots, CH, n_chunks, n_nzrows, n_empty, n_fix, identity, n_wg;
+    int64_t nnz, covered, covered2;
     size_t bytes;
 } spmv_dev_hub;
 /* rowptr_host: the block's row pointers on the host, rowptr_host[0] = their base.  0; -2 not suited (auto_choice: too few entries hit a hub) or

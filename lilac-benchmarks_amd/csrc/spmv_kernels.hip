@@ -659,6 +659,14 @@ k_striped(const int *__restrict__ tptr, const int *__restrict__ rrow, const int 
             f[k] = (int)(c >> 15);
         }
         stripe_load<T, EPL, NTLOAD>(regs, pval, pcol, sb + R * SUB, lane); /* may run into the wave's next tile: same stream */
+        if (abl & 32) { /* timing only: what a layout with one row per lane would leave of a sub-window (loads, LDS gathers, EPL adds) */
+            T t = (T)0;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k)
+                t = t + p[k];
+            acc[0] = acc[0] + t;
+            return;
+        }
         /* lane-local: the sum after the lane's last row end, and whether it has a row end */
         T tailv = (T)0;
         int has = 0;

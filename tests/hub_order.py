@@ -5,7 +5,7 @@ The entry stream (CSR order, values where they lie) is cut into chunks of CH = 1
 takes a chunk in sub-steps of 64 lanes x E entries (E = 2 doubles / 4 floats: one 16-byte load), lane l holding entries
 E l .. E l + E - 1 of the sub-step:
 
-    p[i]   = fl(value * x[column])                (hub or not: the LDS table holds the same x; pads behind the stream: 0 * 0)
+    p[i]   = fl(value * x[column])                (hub or not: the LDS table and the table in memory hold the same x; pads: 0 * 0)
     tailv  = sum of the lane's products after its last row end         (t = t + p[i]; reset to 0 at a row end)
     (sv, sf) = segmented inclusive scan of (tailv, lane has a row end) over the wave, the six DPP steps of spmv_wave.h
     sv     = sf ? sv : sv + carry                  (carry: the open sum of the previous sub-step; 0 at the chunk's start)
@@ -31,7 +31,8 @@ LANES = np.arange(64)
 
 
 class HubPlan(ctypes.Structure):
-    _fields_ = [("K", ctypes.c_int), ("covered", ctypes.c_int64), ("CH", ctypes.c_int), ("n_chunks", ctypes.c_int),
+    _fields_ = [("K", ctypes.c_int), ("K2", ctypes.c_int), ("covered", ctypes.c_int64), ("covered2", ctypes.c_int64),
+                ("CH", ctypes.c_int), ("n_chunks", ctypes.c_int),
                 ("n_nzrows", ctypes.c_int), ("n_empty", ctypes.c_int), ("n_fix", ctypes.c_int), ("identity", ctypes.c_int),
                 ("hubcol", ctypes.POINTER(ctypes.c_int)), ("slot_of", ctypes.POINTER(ctypes.c_int)),
                 ("rank0", ctypes.POINTER(ctypes.c_int)), ("nzrow", ctypes.POINTER(ctypes.c_int)),
@@ -43,17 +44,19 @@ def lds_slots(lib, dtype):
     return lib.spmv_hub_lds_slots(np.dtype(dtype).itemsize)
 
 
-def plan(lib, rs, ci, cols, kmax, ch=1024, min_count=2):
+def plan(lib, rs, ci, cols, kmax, ch=1024, min_count=2, kmax2=0):
     """The plan of csrc/spmv_hub_plan.c as numpy arrays (the column counts are the device's job: np.bincount here)."""
     g = HubPlan()
     cnt = np.ascontiguousarray(np.bincount(ci - 1, minlength=cols).astype(np.int32))
-    lib.spmv_hub_select.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(HubPlan)]
-    assert lib.spmv_hub_select(cnt.ctypes.data, cols, kmax, min_count, ctypes.byref(g)) == 0
+    lib.spmv_hub_select.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(HubPlan)]
+    assert lib.spmv_hub_select(cnt.ctypes.data, cols, kmax, kmax2, min_count, ctypes.byref(g)) == 0
     rsc = np.ascontiguousarray(rs, dtype=np.int32)
     lib.spmv_hub_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(HubPlan)]
     assert lib.spmv_hub_rows(rsc.ctypes.data, int(rsc[0]), rsc.size - 1, ch, ctypes.byref(g)) == 0
     arr = lambda p, n: np.ctypeslib.as_array(p, (n,)).astype(np.int64).copy() if n else np.zeros(0, np.int64)  # noqa: E731
-    out = dict(K=g.K, covered=int(g.covered), CH=g.CH, n_chunks=g.n_chunks, identity=g.identity, hubcol=arr(g.hubcol, g.K),
+    both = arr(g.hubcol, g.K + g.K2)
+    out = dict(K=g.K, K2=g.K2, covered=int(g.covered), covered2=int(g.covered2), CH=g.CH, n_chunks=g.n_chunks, identity=g.identity,
+               hubcol=both[:g.K], hubcol2=both[g.K:],
                slot_of=arr(g.slot_of, cols), rank0=arr(g.rank0, g.n_chunks + 1), nzrow=arr(g.nzrow, g.n_nzrows),
                erow=arr(g.erow, g.n_empty), fix=arr(g.fix, 3 * g.n_fix).reshape(-1, 3))
     assert out["identity"] == int(g.n_empty == 0)

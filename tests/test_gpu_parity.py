@@ -1352,23 +1352,32 @@ def test_hub_is_bit_identical_to_its_documented_order(pkg, backend, planlib, ora
         "npb_like": matgen.npb_like(43, 3000, 150, dtype),
         "long_rows_mixed": matgen.edge_cases(dtype)["long_rows_mixed"][:3],
     }
+    esz = np.dtype(dtype).itemsize
     for name, (rs, ci, a) in cases.items():
         rows, cols = rs.size - 1, int(ci.max())
         x = rng.standard_normal(cols).astype(dtype)
         p = hub_order.plan(planlib, rs, ci, cols, hub_order.lds_slots(planlib, dtype))
         want = hub_order.product(p, rs, ci, a, x)
         got = []
-        for build in range(2):
+        # where an entry's x comes from -- the LDS table, the dense table in memory, x itself -- does not enter the order:
+        # the default tiers (these matrices' hubs all fit the LDS table), then 50 LDS columns + a 200-column table + the rest
+        # from x, then no LDS table at all
+        for build, (cap, tbl) in enumerate([(-1, 2 << 20), (-1, 2 << 20), (50, 200 * esz), (0, 64 * esz)]):
+            backend.set_tuning(23, cap)
+            backend.set_tuning(22, tbl)
             m = backend.matrix(a, rs, ci, rows)
             try:
                 m.set_plan(pkg.PLAN_HUB, 0)
                 inf = m.info()
-                assert inf["plan"] == pkg.PLAN_HUB and inf["plan_param"] == p["K"], (name, inf, p["K"])
-                assert inf["n_launches"] == 1 + (p["K"] > 0) + (len(p["fix"]) > 0 or len(p["erow"]) > 0), (name, inf)
-                for _ in range(3):
+                pt = hub_order.plan(planlib, rs, ci, cols, hub_order.lds_slots(planlib, dtype) if cap < 0 else cap, kmax2=tbl // esz)
+                assert inf["plan"] == pkg.PLAN_HUB and inf["plan_param"] == pt["K"], (name, inf, pt["K"])
+                assert inf["n_launches"] == 1 + (pt["K"] + pt["K2"] > 0) + (len(p["fix"]) > 0 or len(p["erow"]) > 0), (name, inf)
+                for _ in range(3 if build < 2 else 1):
                     got.append(m.spmv_host(x))
             finally:
                 m.close()
+                backend.set_tuning(23, -1)
+                backend.set_tuning(22, 2 << 20)
         for y in got:
             assert np.array_equal(bits(y), bits(want)), "%s: %d rows differ from the documented order" % (
                 name, int(np.count_nonzero(bits(y) != bits(want))))

@@ -33,21 +33,36 @@ def test_hub_plan_and_its_restatement(planlib, oracle, name, dtype):
     rows, nnz = rs.size - 1, int(ci.size)
     cols = int(ci.max())
     x = np.random.default_rng(11).standard_normal(cols).astype(dtype)
-    for kmax in (hub_order.lds_slots(planlib, dtype), 7, 0):
-        p = hub_order.plan(planlib, rs, ci, cols, kmax)
+    for kmax, kmax2 in ((hub_order.lds_slots(planlib, dtype), 0), (7, 0), (0, 0), (7, 20), (5, 1 << 20), (0, 9)):
+        p = hub_order.plan(planlib, rs, ci, cols, kmax, kmax2=kmax2)
         # ---- the hubs: the kmax most referenced columns, none referenced once, ascending, slot_of their inverse
         cnt = np.bincount(ci - 1, minlength=cols)
         K = p["K"]
         assert K <= kmax and np.all(np.diff(p["hubcol"]) > 0)
-        assert np.array_equal(np.nonzero(p["slot_of"] >= 0)[0], p["hubcol"]) and np.array_equal(p["slot_of"][p["hubcol"]], np.arange(K))
+        assert np.array_equal(p["slot_of"][p["hubcol"]], np.arange(K))
+        assert np.array_equal(np.nonzero((p["slot_of"] >= 0) & (p["slot_of"] < K))[0], p["hubcol"])
         if K:
             assert cnt[p["hubcol"]].min() >= 2
             rest = np.delete(cnt, p["hubcol"])
-            if rest.size and K == kmax:
+            if kmax2:
+                pass  # with a second tier the left-over columns are judged below
+            elif rest.size and K == kmax:
                 assert rest.max() <= cnt[p["hubcol"]].min()  # nobody left out is referenced more than a hub
             elif rest.size:
                 assert rest.max() < 2  # room left: every column referenced twice or more is in
         assert p["covered"] == int(cnt[p["hubcol"]].sum())
+        # ---- tier 1 (the dense table in memory): the kmax2 most referenced of the REST, slots behind tier 0's
+        K2, h2 = p["K2"], p["hubcol2"]
+        assert K2 <= kmax2 and np.all(np.diff(h2) > 0) and not np.intersect1d(h2, p["hubcol"]).size
+        assert np.array_equal(p["slot_of"][h2], K + np.arange(K2)) and int(np.count_nonzero(p["slot_of"] >= 0)) == K + K2
+        assert p["covered2"] == int(cnt[h2].sum())
+        if K2:
+            assert cnt[h2].min() >= 2
+            rest2 = np.delete(cnt, np.concatenate([p["hubcol"], h2]))
+            if rest2.size:
+                assert rest2.max() <= cnt[h2].min() if K2 == kmax2 else rest2.max() < 2
+            if K:
+                assert cnt[h2].max() <= cnt[p["hubcol"]].min()  # nobody in tier 1 is referenced more than a tier-0 hub
         # ---- the rows
         CH = p["CH"]
         lens = np.diff(rs)
