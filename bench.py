@@ -51,7 +51,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MEASURED_READ_CEILING_GBS = 6386.6
+# what a kernel that only READS reaches with k_striped's launch and load shapes (256 workgroups x 16 waves, per-wave streams,
+# non-temporal 16-byte loads, four register sets in flight) on class C's 366-MB packed stream: tools/ntstream.hip,
+# profiles/r04_ntstream_read_ceilings.log (7397 / 7401 GB/s in two runs; 868 MB: 6906 / 6955; 6.9 GB: 6581 / 6687)
+MEASURED_READ_CEILING_GBS = 7400.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ZETA_D = 52.514532105794  # cg.f:122-163
 
@@ -188,6 +191,8 @@ def other_configs(pkg, be, np, line):
         levels += lv
     bfs_s = time.perf_counter() - t1
     st = be.stats()
+    bfs_attr = {"bfs_time_in_spmv_s": round(st["t_total"], 4), "bfs_upload_s": round(st["t_upload"], 4),
+                "bfs_abi_ms_per_call": round((st["t_total"] - st["t_upload"]) / max(1, st["calls"]) * 1e3, 4)}
     be.release()
     dm = be.matrix(a, rs, ci, g.rows)
     inf = dm.info()
@@ -199,19 +204,28 @@ def other_configs(pkg, be, np, line):
     check_rows(np, a, rs, ci, x, be.d2h(np.empty(g.rows), dy), "rmat 20 kernel")
     dm.close(), be.free(dx), be.free(dy)
     iters = 20
+    be.reset_stats()
     t1 = time.perf_counter()
     pr, err = C.pagerank(g, be.harness_fn(), iters)
     pr_ms = (time.perf_counter() - t1) / iters * 1e3
+    st = be.stats()
+    pr_attr = {"pagerank_time_in_spmv_s": round(st["t_total"], 4), "pagerank_upload_s": round(st["t_upload"], 4),
+               "pagerank_abi_ms_per_call": round((st["t_total"] - st["t_upload"]) / max(1, st["calls"]) * 1e3, 4),
+               "pagerank_spmv_calls": int(st["calls"])}
     assert np.all(np.isfinite(pr)) and np.all(pr >= 0.0) and 0.0 < float(pr.sum()) <= 1.0 + 1e-9  # dangling vertices leak rank (main.cpp:128-149 does not redistribute it)
     be.release()
-    line["graphs_rmat20"] = {
+    line["graphs_rmat20"] = dict(bfs_attr, **pr_attr)
+    line["graphs_rmat20"].update({
         "rows": g.rows, "nnz": int(g.nnz), "plan": pkg.abi.PLAN_NAMES[inf["plan"]], "spmv_us": round(ms * 1e3, 2),
         "frac": round(inf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "bfs_s": round(bfs_s, 4), "bfs_sources": int(len(sources)), "bfs_spmv_calls": int(levels), "bfs_uploads": int(st["uploads"]),
         "pagerank_ms_per_iter": round(pr_ms, 3), "pagerank_iters": iters, "setup_s": round(time.time() - t0, 1),
+        "attribution": "x_time_in_spmv_s = seconds between entry to and return from spmv_harness_ (the library's own clock, the one-time upload "
+                       "included); x_abi_ms_per_call = the same without the upload, per call: what is left "
+                       "of bfs_s and pagerank_ms_per_iter is the caller counterpart's own loops (host/callers.c)",
         "what": "bfs/bfs.cc:36-68 and pagerank/main.cpp:128-149 call patterns through spmv_harness_ (first call uploads); "
                 "frontiers are bit-exact by construction (integer-valued products), checked in tests/test_gpu_parity.py",
-    }
+    })
     C.free(g)
     # ---- parboil: the two bundled datasets, 50 products each through f_spmv_harness_ under the default dispatch
     pb = {}
@@ -242,12 +256,17 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cls", default=None, help="override the NPB class (default: C at N=1, D at N>1)")
-    ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered|tiled|striped")
+    ap.add_argument("--plan", default="auto", help="auto|stream|vector:L|binned|ordered|tiled|striped|blocked|hub")
+    ap.add_argument("--prewarm", type=int, default=600, help="untimed launches before the W warm-up steps (a FIXED count: the first "
+                    "hundreds of launches over a fresh layout run 1-3 us slower, profiles/r03_coldstart_first_300_launches.log); "
+                    "the figure after the W warm-up steps alone is reported beside the headline in `after_warmup_only`")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-npb", action="store_true", help="skip the full NPB CG runs through the ABI")
     ap.add_argument("--no-configs", action="store_true", help="skip the sparsebench / graphs / parboil objects (N = 1)")
     ap.add_argument("--cpu-iters", type=int, default=10, help="timed CG iterations of the CPU sample")
     ap.add_argument("--no-scale-ref", action="store_true", help="skip the class D single-GPU reference point at N=1")
+    ap.add_argument("--scale-ref-cls", default=None, help="class of the scale_ref object (default: D, the N > 1 workload, when the "
+                    "headline is class C; naming a class runs it whatever the headline's class -- the tests use B)")
     ap.add_argument("--npb-repeats", type=int, default=5, help="runs of the full NPB CG benchmark at N=1; the median is reported")
     args = ap.parse_args()
 
@@ -297,6 +316,7 @@ def main():
     # =============================================================== the kernel figure
     t0 = time.time()
     cold = None
+    after_warmup_only = None
     gather = None
     rank_ms = None
     devices_used = None
@@ -318,8 +338,7 @@ def main():
         info = dms[0].info()
         infos = [dm.info() for dm in dms]
         PREWARM = 0
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.05 or PREWARM < 12:
+        for _ in range(max(12, args.prewarm // 6) // 12):  # a fixed count here too (class D row blocks: fewer, longer launches)
             be.time_multi(dms, dxs, dys, 12)
             PREWARM += 12
         be.time_multi(dms, dxs, dys, max(1, args.warmup))
@@ -352,7 +371,8 @@ def main():
         if args.plan != "auto":
             name, _, par = args.plan.partition(":")
             plan = {"stream": pkg.PLAN_STREAM, "vector": pkg.PLAN_VECTOR, "binned": pkg.PLAN_BINNED,
-                    "ordered": pkg.PLAN_ORDERED, "tiled": pkg.PLAN_TILED, "striped": pkg.PLAN_STRIPED}[name]
+                    "ordered": pkg.PLAN_ORDERED, "tiled": pkg.PLAN_TILED, "striped": pkg.PLAN_STRIPED,
+                    "blocked": pkg.PLAN_BLOCKED, "hub": pkg.PLAN_HUB}[name]
             dm.set_plan(plan, int(par) if par else 0)
         info = dm.info()
         x = np.random.default_rng(12345).standard_normal(m.na + 2)  # same on every rank: x is replicated
@@ -366,10 +386,17 @@ def main():
                 "frac": round(info["algorithmic_bytes"] / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "what": "the first 20 launches after the upload of the matrix, nothing run before them (DESIGN.md 4.4: "
                         "the first launches over a fresh layout run slower)"}
-        # untimed: a fixed pre-warm, then the W warm-up steps asked for; the line reports both
-        PREWARM = 20
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.05 or PREWARM < 32:  # ~50 ms of back-to-back products
+        # what the command line alone asks for: W warm-up steps, then K timed ones (the 20 cold launches came before them)
+        for _ in range(args.warmup):
+            dm.spmv_device(dx, dy)
+        be.synchronize(device)
+        aw_ms = dm.time_device(dx, dy, args.steps) / args.steps
+        after_warmup_only = {"launch_us": round(aw_ms * 1e3, 3), "value": round(2.0 * m.nnz / (aw_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s",
+                             "frac": round(info["algorithmic_bytes"] / (aw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "what": "this rank's K steps timed right after the 20 cold launches and the W warm-up steps, before the fixed pre-warm"}
+        # untimed: a FIXED pre-warm (--prewarm launches), then the W warm-up steps again; the line reports both figures
+        PREWARM = 20 + args.warmup + args.steps
+        for _ in range(max(0, args.prewarm) // 12):
             dm.time_device(dx, dy, 12)
             PREWARM += 12
         for _ in range(args.warmup):
@@ -500,8 +527,8 @@ def main():
                          ("one process per GPU (torch.distributed, %s)" % backend_name if n_gpus > 1 else "one process"),
             "rank_ms_per_step": rank_ms,
             "untimed_steps_before_timing": PREWARM + args.warmup,
-            "prewarm": "%d untimed steps (the 20 `cold` launches, then ~50 ms of back-to-back products) before the %d warm-up steps; "
-                       "the cold figure is in `cold`" % (PREWARM, args.warmup),
+            "prewarm": "%d untimed steps (the 20 `cold` launches, the steps of `after_warmup_only`, then a fixed %d launches) before the "
+                       "%d warm-up steps; the figures without them are in `cold` and `after_warmup_only`" % (PREWARM, args.prewarm, args.warmup),
         },
         "roofline": {
             "bound": "hbm",
@@ -517,13 +544,16 @@ def main():
             "launch_us": round(launch_ms * 1e3, 3),
             "scope": "the slowest row block (its own algorithmic bytes over its own launch time)" if n_gpus > 1 else "whole matrix",
             # context, not the contract's fraction: what a kernel that only READS memory reaches on an MI355X
-            # (tools/streambench.hip, 24 KiB per workgroup: profiles/r01_streambench_read_ceilings.log)
             "measured_read_ceiling": {"GB/s": MEASURED_READ_CEILING_GBS, "frac_of_it": round(achieved / MEASURED_READ_CEILING_GBS, 4),
-                                      "source": "profiles/r01_streambench_read_ceilings.log (stored figure)"},
+                                      "of": "algorithmic bytes; the kernel's own stream is 10 B per nonzero where the algorithmic count is 12",
+                                      "source": "profiles/r04_ntstream_read_ceilings.log (stored figure: a read-only kernel with "
+                                                "k_striped's launch and load shapes on a stream of class C's size)"},
         },
     }
     if cold is not None:
         line["cold"] = cold
+    if after_warmup_only is not None:
+        line["after_warmup_only"] = after_warmup_only
     if devices_used is not None:
         line["config"]["devices_used"] = devices_used
         if devices_used < n_gpus:
@@ -544,6 +574,17 @@ def main():
         if rank == 0 and not args.no_npb:
             obj, mfull = npb_through_the_abi(pkg, be, cls, n_gpus, 1, np)
             line["npb_cg"] = obj
+            # the same benchmark with conj_grad resident on the GPUs: one row block per GPU, the scalars through pinned host
+            # memory, the slices of p peer to peer (spmv_hip_cg_create_multi); no collective library
+            vis = be.device_count()
+            rdm = mfull.run_cg_device_parts(be, n_gpus, min(n_gpus, vis))
+            line["npb_cg_device"] = {
+                "class": cls, "mops": round(rdm["mops"], 2), "time_s": round(rdm["t_bench"], 4), "zeta": rdm["zeta"], "err": rdm["err"],
+                "verified": bool(rdm["verified"]), "row_partitions": n_gpus, "devices_used": min(n_gpus, vis),
+                "path": "spmv_hip_cg_create_multi: every GPU keeps its row block of A, its slices of x, z, q, r and a full copy of p; per CG "
+                        "iteration two scalars cross through pinned host memory (added in part order) and every part pushes its slice of p "
+                        "to the others with hipMemcpyPeerAsync; one host thread issues everything",
+            }
             if inproc:
                 # the gather-inclusive step, one process: K ABI calls on the full matrix (x to every GPU, kernels, y slices back)
                 xx = np.random.default_rng(12345).standard_normal(mfull.na + 2)
@@ -612,11 +653,12 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_configs:
         other_configs(pkg, be, np, line)
 
-    if rank == 0 and n_gpus == 1 and cls == "C" and not args.no_scale_ref:
+    sr_cls = args.scale_ref_cls or ("D" if cls == "C" else None)
+    if rank == 0 and n_gpus == 1 and sr_cls and not args.no_scale_ref:
         # the workload of the N > 1 runs (class D, BASELINE configs[4]) on this one GPU, whole matrix:
         # the like-for-like 1-GPU point for the strong-scaling series (the headline above stays class C)
         t0 = time.time()
-        md = pkg.npb.NpbMatrix("D")
+        md = pkg.npb.NpbMatrix(sr_cls)
         t_gen = time.time() - t0
         t0 = time.time()
         dmd = be.matrix(md.a, md.rowstr, md.colidx, md.rows, device=device, cols_hint=md.na)
@@ -631,7 +673,7 @@ def main():
         ksteps = 20
         msd = dmd.time_device(dxd, dyd, ksteps) / ksteps
         line["scale_ref"] = {
-            "workload": "NPB CG class D, whole matrix on 1 GPU (what the N > 1 runs partition)",
+            "workload": "NPB CG class %s, whole matrix on 1 GPU (what the N > 1 runs partition)" % sr_cls, "class": sr_cls,
             "value": round(2.0 * md.nnz / (msd * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "ms_per_step": round(msd, 6),
             "steps": ksteps, "warmup": 40, "nnz": int(md.nnz), "plan": pkg.abi.PLAN_NAMES[infd["plan"]],
             "roofline_frac": round(infd["algorithmic_bytes"] / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -640,7 +682,7 @@ def main():
             "launches_per_step": infd["n_launches"], "workgroups": infd["n_blocks"],
         }
         try:  # stored PMC figure of this workload (profiles/traffic.json), not measured by this run
-            ent = json.load(open(tpath)).get("D/%s" % pkg.abi.PLAN_NAMES[infd["plan"]], {})
+            ent = json.load(open(tpath)).get("%s/%s" % (sr_cls, pkg.abi.PLAN_NAMES[infd["plan"]]), {})
             line["scale_ref"]["traffic"] = ent.get("hbm_bytes_per_launch")
             line["scale_ref"]["traffic_source"] = ent.get("source")
         except Exception:
@@ -648,6 +690,23 @@ def main():
         dmd.close()
         be.free(dxd, device)
         be.free(dyd, device)
+        if not args.no_npb:
+            # the first point of the MOp/s series (the metric at N > 1 is NPB CG class D): the complete benchmark on this one
+            # GPU, through the drop-in ABI and through the device-resident CG (cg.f:395-402; zeta against cg.f:122-163)
+            be.reset_stats()
+            rd = md.run_cg(be.harness_fn())
+            std = be.stats()
+            line["scale_ref"]["npb_cg"] = npb_cg_object(md, be, rd, std, [rd], sr_cls,
+                                                        "spmv_harness_ ABI: host x/y every call (PCIe round trip), host vector loops on 1 core")
+            if sr_cls == "D":
+                line["scale_ref"]["npb_cg"]["zeta_reference"] = ZETA_D
+            be.release()
+            rdd = md.run_cg_device(be)
+            line["scale_ref"]["npb_cg_device"] = {
+                "class": sr_cls, "mops": round(rdd["mops"], 2), "time_s": round(rdd["t_bench"], 4), "zeta": rdd["zeta"], "err": rdd["err"],
+                "verified": bool(rdd["verified"]),
+                "path": "spmv_hip_cg_* opt-in entry points: vectors resident in HBM, 4 kernels per CG iteration",
+            }
         md.close()
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu:

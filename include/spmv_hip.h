@@ -154,6 +154,12 @@ void spmv_hip_host_unregister(void *p);
  */
 typedef struct spmv_hip_cg spmv_hip_cg;
 spmv_hip_cg *spmv_hip_cg_create(spmv_hip_matrix *m);
+/* The same step over `nparts` row partitions of one square FP64 matrix (round 4): parts[k] = rows [b_k, b_k+1) in order, every
+ * part created with the full column range (cols_hint = the order of the matrix), each on its own GPU (or wrapped onto fewer).
+ * Each part keeps its row slices of x, z, q, r and a full copy of p; per CG iteration the parts exchange two scalars through
+ * pinned host memory (added in part order: reproducible) and their slices of p by hipMemcpyPeerAsync -- no collective library.
+ * The handle is used with every other spmv_hip_cg_* entry point as a one-GPU handle is. */
+spmv_hip_cg *spmv_hip_cg_create_multi(spmv_hip_matrix **parts, int nparts);
 void spmv_hip_cg_destroy(spmv_hip_cg *c);
 int spmv_hip_cg_set_x(spmv_hip_cg *c, const double *x_host);   /* upload x[0..rows) */
 int spmv_hip_cg_fill_x(spmv_hip_cg *c, double value);          /* x = value (cg.f:216-218) */

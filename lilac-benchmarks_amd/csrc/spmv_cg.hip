@@ -17,6 +17,21 @@
  * All reductions are two-level with a fixed order (no atomics): results are reproducible run to
  * run.  They are NOT the Fortran loops' left-to-right sums, so zeta agrees with the reference to
  * ~1e-13 relative rather than bit for bit; NPB's own criterion is 1e-10 (cg.f:363-368).
+ *
+ * Round 4: the same step over N ROW PARTITIONS, one per GPU (spmv_hip_cg_create_multi; SURVEY.md 8(e) x 8(f)1).  Part k
+ * holds its row block of A (x replicated: the SpMV's own partition), its row slices of x, z, q, r and a FULL copy of p.
+ * No collective library; per CG iteration three exchanges, each closed by an event barrier between the parts' streams:
+ *   1. q_k = A_k p;  d_k = p_k . q_k  -> one double per part in pinned host memory
+ *   2. every part adds d_0 .. d_{N-1} and rho_0 .. rho_{N-1} in PART ORDER (the same bits everywhere), alpha = rho / d;
+ *      z_k, r_k updated;  rho'_k = r_k . r_k -> pinned host memory
+ *   3. beta from the rho' and rho slots, part order;  p_k = r_k + beta p_k written into the part's own copy of p, then
+ *      pushed to the other N - 1 copies with hipMemcpyPeerAsync on the part's stream (class D over 8 GPUs: 1.5 MB to 7
+ *      peers each, point to point over xGMI)
+ * Results are a function of the partition (N and the row bounds), reproducible run to run; zeta agrees with the one-GPU
+ * run to ~1e-13.  One host thread issues everything (per iteration and part: 8 launches, N - 1 copies, 3 event records
+ * and waits through one hub stream): at N = 8 that is ~200 API calls per iteration -- expect the host, not the GPUs, to
+ * bound class D at 8 GPUs.  UNMEASURED on more than one GPU: every test runs the parts wrapped onto one device, where
+ * the peer copy degenerates to a device-to-device copy.
  */
 #include <hip/hip_runtime.h>
 
@@ -182,7 +197,79 @@ __global__ void __launch_bounds__(256) k_cg_scale(double *__restrict__ x, const 
         x[i] = z ? scale * z[i] : scale;
 }
 
+/* ---- the row-partitioned step: scalars cross the parts through pinned host memory ---- */
+
+/* *host_slot = the sum of this part's partials (sum_partials' order): one wave */
+__global__ void __launch_bounds__(64) k_cgm_scalar(const double *__restrict__ part, int nb, double *host_slot)
+{
+    const double s = sum_partials(part, nb);
+    if (threadIdx.x == 0)
+        *host_slot = s;
+}
+
+/* out[0] = a[0] + ... + a[n-1], out[1] = b[0] + ... + b[n-1], in part order: one thread reads the pinned slots once, so that
+ * the vector kernels behind it find the two scalars in device memory (every wave reading 2 n doubles across PCIe would cost
+ * more than the kernels themselves) */
+__global__ void __launch_bounds__(64) k_cgm_combine(const double *a, const double *b, int n, double *__restrict__ out)
+{
+    if (threadIdx.x != 0)
+        return;
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < n; ++k) {
+        sa += a[k];
+        sb += b[k];
+    }
+    out[0] = sa;
+    out[1] = sb;
+}
+
+/* alpha = sc[0] / sc[1]; z += alpha p; r -= alpha q; rho_new_part[b] = sum r*r over block b   (cg.f:581-605) */
+__global__ void __launch_bounds__(256) k_cgm_axpy(double *__restrict__ z, double *__restrict__ r, const double *__restrict__ p,
+                                                  const double *__restrict__ q, const double *__restrict__ sc,
+                                                  double *__restrict__ rho_new_part, int n)
+{
+    __shared__ double s_w[4];
+    const double alpha = sc[0] / sc[1];
+    double acc = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        const int i = blockIdx.x * VB + k * 256 + threadIdx.x;
+        if (i < n) {
+            z[i] = z[i] + alpha * p[i];
+            const double ri = r[i] - alpha * q[i];
+            r[i] = ri;
+            acc += ri * ri;
+        }
+    }
+    const double t = block_sum(acc, s_w);
+    if (threadIdx.x == 0)
+        rho_new_part[blockIdx.x] = t;
+}
+
+/* beta = sc[0] / sc[1]; p = r + beta p   (cg.f:610-617) */
+__global__ void __launch_bounds__(256) k_cgm_pupd(double *__restrict__ p, const double *__restrict__ r, const double *__restrict__ sc, int n)
+{
+    const double beta = sc[0] / sc[1];
+    for (int k = 0; k < 4; ++k) {
+        const int i = blockIdx.x * VB + k * 256 + threadIdx.x;
+        if (i < n)
+            p[i] = r[i] + beta * p[i];
+    }
+}
+
 } // namespace
+
+/* one row partition of the multi-GPU step */
+struct cg_part {
+    spmv_hip_matrix *m = nullptr;
+    int device = 0;
+    int r0 = 0, rows = 0, nb = 0;
+    double *pfull = nullptr;                                 /* n + 16: every part's copy of p (and of z for r = A z)   */
+    double *x = nullptr, *z = nullptr, *q = nullptr, *r = nullptr; /* rows + 16: the part's row slices                  */
+    double *part[4] = {nullptr, nullptr, nullptr, nullptr};  /* local partials: rho (two generations), d, scratch       */
+    double *sc = nullptr;                                    /* 4 doubles: the combined scalars of the current step     */
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+};
 
 struct spmv_hip_cg {
     spmv_hip_matrix *m = nullptr;
@@ -193,7 +280,197 @@ struct spmv_hip_cg {
     double *part[4] = {nullptr, nullptr, nullptr, nullptr}; /* rho (two generations), d, scratch */
     double *h_part = nullptr;                               /* pinned, 2*nb */
     hipStream_t stream = nullptr;
+    /* row-partitioned mode (spmv_hip_cg_create_multi): np > 0 */
+    int np = 0;
+    cg_part *parts = nullptr;
+    double *h_slots = nullptr; /* pinned: [3][np] -- rho generation 0, rho generation 1, d: one double per part */
+    hipEvent_t join = nullptr;
 };
+
+namespace {
+
+/* Every part's stream continues only after every part's stream has reached this point: N records, N - 1 waits on the hub
+ * (part 0's stream), one record there, N - 1 waits on it.  Events are captured by the waits at the time of the call, so
+ * the same event objects serve every barrier. */
+int multi_barrier(spmv_hip_cg *c)
+{
+    cg_part *P = c->parts;
+    for (int k = 0; k < c->np; ++k) {
+        if (hipSetDevice(P[k].device) != hipSuccess || hipEventRecord(P[k].ev, P[k].stream) != hipSuccess)
+            return -1;
+    }
+    if (hipSetDevice(P[0].device) != hipSuccess)
+        return -1;
+    for (int k = 1; k < c->np; ++k)
+        if (hipStreamWaitEvent(P[0].stream, P[k].ev, 0) != hipSuccess)
+            return -1;
+    if (c->np > 1 && hipEventRecord(c->join, P[0].stream) != hipSuccess)
+        return -1;
+    for (int k = 1; k < c->np; ++k) {
+        if (hipSetDevice(P[k].device) != hipSuccess || hipStreamWaitEvent(P[k].stream, c->join, 0) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+
+/* part k's row slice of `which` (0: the part's own copy of p, 1: z) into every OTHER part's full vector */
+int multi_push_slice(spmv_hip_cg *c, int k, const double *src)
+{
+    cg_part *P = c->parts;
+    if (P[k].rows == 0)
+        return 0;
+    if (hipSetDevice(P[k].device) != hipSuccess)
+        return -1;
+    for (int j = 0; j < c->np; ++j) {
+        if (j == k)
+            continue;
+        if (hipMemcpyPeerAsync(P[j].pfull + P[k].r0, P[j].device, src, P[k].device, (size_t)P[k].rows * sizeof(double),
+                               P[k].stream) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+
+void multi_free(spmv_hip_cg *c)
+{
+    for (int k = 0; k < c->np; ++k) {
+        cg_part &p = c->parts[k];
+        (void)hipSetDevice(p.device);
+        if (p.stream)
+            (void)hipStreamSynchronize(p.stream);
+        double *bufs[] = {p.pfull, p.x, p.z, p.q, p.r, p.part[0], p.part[1], p.part[2], p.part[3], p.sc};
+        for (double *b : bufs)
+            if (b)
+                (void)hipFree(b);
+        if (p.ev)
+            (void)hipEventDestroy(p.ev);
+        if (p.stream)
+            (void)hipStreamDestroy(p.stream);
+    }
+    delete[] c->parts;
+    c->parts = nullptr;
+    if (c->h_slots)
+        (void)hipHostFree(c->h_slots);
+    if (c->join)
+        (void)hipEventDestroy(c->join);
+}
+
+#define CGM(expr)                                                                                       \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            spmv_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            return -1;                                                                                  \
+        }                                                                                               \
+    } while (0)
+
+/* conj_grad over the row partitions; see the head of this file */
+int multi_conj_grad(spmv_hip_cg *c, int cgitmax, double *rnorm)
+{
+    cg_part *P = c->parts;
+    const int np = c->np;
+    double *h_rho[2] = {c->h_slots, c->h_slots + np}, *h_d = c->h_slots + 2 * np;
+    int gen = 0; /* h_rho[gen]: rho of the current residual */
+    /* r = p = x, z = q = 0, rho (cg.f:492-506); every copy of p complete before the first product */
+    for (int k = 0; k < np; ++k) {
+        CGM(hipSetDevice(P[k].device));
+        if (P[k].rows > 0)
+            hipLaunchKernelGGL(k_cg_init, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].x, P[k].z, P[k].pfull + P[k].r0, P[k].q,
+                               P[k].r, P[k].part[0], P[k].rows);
+        hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, P[k].stream, P[k].part[0], P[k].nb, h_rho[gen] + k);
+        CGM(hipGetLastError());
+        if (multi_push_slice(c, k, P[k].pfull + P[k].r0))
+            return -1;
+    }
+    if (multi_barrier(c))
+        return -1;
+    for (int it = 0; it < cgitmax; ++it) {
+        /* 1. q_k = A_k p and d_k = p_k . q_k (cg.f:532, 573-577) */
+        for (int k = 0; k < np; ++k) {
+            CGM(hipSetDevice(P[k].device));
+            int nd = 0;
+            if (P[k].rows > 0) {
+                nd = spmvd_spmv_dot(P[k].m, P[k].pfull, P[k].q, P[k].stream, P[k].pfull + P[k].r0, P[k].part[2]);
+                if (nd < 0)
+                    return -1;
+                if (nd == 0) {
+                    if (spmv_hip_spmv_device(P[k].m, P[k].pfull, P[k].q, P[k].stream))
+                        return -1;
+                    CGM(hipSetDevice(P[k].device));
+                    hipLaunchKernelGGL(k_cg_dot, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].pfull + P[k].r0, P[k].q, P[k].part[2],
+                                       (const double *)nullptr, (const double *)nullptr, (double *)nullptr, P[k].rows);
+                    nd = P[k].nb;
+                }
+            }
+            hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, P[k].stream, P[k].part[2], nd, h_d + k);
+            CGM(hipGetLastError());
+        }
+        if (multi_barrier(c))
+            return -1;
+        /* 2. alpha = rho / d; z, r; rho' (cg.f:581-605) */
+        for (int k = 0; k < np; ++k) {
+            CGM(hipSetDevice(P[k].device));
+            hipLaunchKernelGGL(k_cgm_combine, dim3(1), dim3(64), 0, P[k].stream, h_rho[gen], h_d, np, P[k].sc);
+            if (P[k].rows > 0)
+                hipLaunchKernelGGL(k_cgm_axpy, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].z, P[k].r, P[k].pfull + P[k].r0, P[k].q,
+                                   P[k].sc, P[k].part[1], P[k].rows);
+            hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, P[k].stream, P[k].part[1], P[k].nb, h_rho[gen ^ 1] + k);
+            CGM(hipGetLastError());
+        }
+        if (multi_barrier(c))
+            return -1;
+        /* 3. beta = rho' / rho; p = r + beta p, into every copy of p (cg.f:610-617) */
+        for (int k = 0; k < np; ++k) {
+            CGM(hipSetDevice(P[k].device));
+            hipLaunchKernelGGL(k_cgm_combine, dim3(1), dim3(64), 0, P[k].stream, h_rho[gen ^ 1], h_rho[gen], np, P[k].sc + 2);
+            if (P[k].rows > 0)
+                hipLaunchKernelGGL(k_cgm_pupd, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].pfull + P[k].r0, P[k].r, P[k].sc + 2,
+                                   P[k].rows);
+            CGM(hipGetLastError());
+            if (multi_push_slice(c, k, P[k].pfull + P[k].r0))
+                return -1;
+        }
+        if (multi_barrier(c))
+            return -1;
+        gen ^= 1;
+    }
+    /* r = A z (cg.f:628): z gathered into every part's full vector (p is dead until the next call's init), then ||x - r|| */
+    for (int k = 0; k < np; ++k) {
+        CGM(hipSetDevice(P[k].device));
+        if (P[k].rows > 0)
+            CGM(hipMemcpyAsync(P[k].pfull + P[k].r0, P[k].z, (size_t)P[k].rows * sizeof(double), hipMemcpyDeviceToDevice, P[k].stream));
+        if (multi_push_slice(c, k, P[k].z))
+            return -1;
+    }
+    if (multi_barrier(c))
+        return -1;
+    double s = 0.0;
+    for (int k = 0; k < np; ++k) {
+        if (P[k].rows == 0)
+            continue;
+        if (spmv_hip_spmv_device(P[k].m, P[k].pfull, P[k].r, P[k].stream))
+            return -1;
+        CGM(hipSetDevice(P[k].device));
+        hipLaunchKernelGGL(k_cg_resid, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].x, P[k].r, P[k].part[3], P[k].rows);
+        CGM(hipGetLastError());
+        CGM(hipMemcpyAsync(c->h_part + P[k].r0 / VB + k, P[k].part[3], (size_t)P[k].nb * sizeof(double), hipMemcpyDeviceToHost, P[k].stream));
+    }
+    for (int k = 0; k < np; ++k) {
+        CGM(hipSetDevice(P[k].device));
+        CGM(hipStreamSynchronize(P[k].stream));
+        const double *hp = c->h_part + P[k].r0 / VB + k; /* part k's partials: at most rows_k / VB + 1 of them */
+        for (int i = 0; i < (P[k].rows > 0 ? P[k].nb : 0); ++i)
+            s += hp[i];
+    }
+    /* a barrier again: nobody starts the next call's init (which rewrites p) while a neighbour still multiplies */
+    if (multi_barrier(c))
+        return -1;
+    if (rnorm)
+        *rnorm = sqrt(s);
+    return 0;
+}
+
+} // namespace
 
 #define CGCHK(expr)                                                                          \
     do {                                                                                     \
@@ -211,6 +488,13 @@ void spmv_hip_cg_destroy(spmv_hip_cg *c)
 {
     if (!c)
         return;
+    if (c->np > 0) {
+        multi_free(c);
+        if (c->h_part)
+            (void)hipHostFree(c->h_part);
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
@@ -261,8 +545,101 @@ spmv_hip_cg *spmv_hip_cg_create(spmv_hip_matrix *m)
     return c;
 }
 
+/*
+ * The same step over `nparts` row partitions of one square FP64 matrix: parts[k] holds rows [b_k, b_k+1) (in order, b_0 = 0,
+ * b_nparts = cols; spmv_hip_partition_rows makes such bounds) with the full column range (cols_hint = the matrix order), each
+ * on the device it was created on -- several parts may share a device (a rehearsal of the N-GPU path on fewer GPUs).
+ * Every other spmv_hip_cg_* entry point takes the handle as it takes a one-GPU one.
+ */
+spmv_hip_cg *spmv_hip_cg_create_multi(spmv_hip_matrix **parts, int nparts)
+{
+    if (!parts || nparts < 1 || nparts > 64) {
+        spmv_set_error("spmv_hip_cg_create_multi: 1 to 64 row partitions, got %d", nparts);
+        return nullptr;
+    }
+    spmv_hip_cg *c = new spmv_hip_cg();
+    c->np = nparts;
+    c->parts = new cg_part[nparts];
+    int r0 = 0, n = -1;
+    bool ok = true;
+    for (int k = 0; k < nparts && ok; ++k) {
+        spmv_hip_info inf;
+        if (!parts[k] || spmv_hip_matrix_info(parts[k], &inf)) {
+            spmv_set_error("spmv_hip_cg_create_multi: part %d is not a matrix", k);
+            ok = false;
+            break;
+        }
+        if (n < 0)
+            n = inf.cols;
+        if (inf.elem_size != 8 || inf.cols != n) {
+            spmv_set_error("spmv_hip_cg_create_multi: part %d: FP64 row blocks of one matrix wanted (elem %d, cols %d against %d)", k,
+                           inf.elem_size, inf.cols, n);
+            ok = false;
+            break;
+        }
+        cg_part &p = c->parts[k];
+        p.m = parts[k], p.device = inf.device, p.r0 = r0, p.rows = inf.rows, p.nb = (inf.rows + VB - 1) / VB;
+        r0 += inf.rows;
+    }
+    if (ok && r0 != n) {
+        spmv_set_error("spmv_hip_cg_create_multi: the parts hold %d rows of a matrix with %d columns (a square matrix, every row once)", r0, n);
+        ok = false;
+    }
+    c->n = n;
+    c->nb = n > 0 ? (n + VB - 1) / VB : 0;
+    for (int k = 0; k < nparts && ok; ++k) {
+        cg_part &p = c->parts[k];
+        ok = hipSetDevice(p.device) == hipSuccess;
+        for (int j = 0; j < nparts && ok; ++j) /* point-to-point copies between the parts' devices (xGMI); already on: fine */
+            if (c->parts[j].device != p.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, p.device, c->parts[j].device) == hipSuccess && can) {
+                    (void)hipDeviceEnablePeerAccess(c->parts[j].device, 0);
+                    (void)hipGetLastError();
+                }
+            }
+        ok = ok && hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p.ev, hipEventDisableTiming) == hipSuccess;
+        const size_t vfull = ((size_t)n + 16) * sizeof(double), vloc = ((size_t)p.rows + 16) * sizeof(double);
+        ok = ok && hipMalloc((void **)&p.pfull, vfull) == hipSuccess && hipMemset(p.pfull, 0, vfull) == hipSuccess;
+        double **vecs[] = {&p.x, &p.z, &p.q, &p.r};
+        for (double **v : vecs)
+            ok = ok && hipMalloc((void **)v, vloc) == hipSuccess && hipMemset(*v, 0, vloc) == hipSuccess;
+        for (int j = 0; j < 4; ++j) /* as in the one-GPU step: room for one partial per wave range of the STRIPED plan */
+            ok = ok && hipMalloc((void **)&p.part[j], ((size_t)p.rows + 64) * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&p.sc, 4 * sizeof(double)) == hipSuccess;
+    }
+    if (ok) {
+        ok = hipSetDevice(c->parts[0].device) == hipSuccess && hipEventCreateWithFlags(&c->join, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&c->h_slots, (size_t)(3 * nparts + 2) * sizeof(double),
+                                 hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess; /* every GPU reads and writes it */
+        /* partials of the residual and of the two norms: part k's at r0_k / VB + k (at most rows_k / VB + 1 each) */
+        ok = ok && hipHostMalloc((void **)&c->h_part, (size_t)(2 * (c->nb + nparts) + 2) * sizeof(double), hipHostMallocDefault) == hipSuccess;
+        if (!ok)
+            spmv_set_error("spmv_hip_cg_create_multi: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (!ok) {
+        spmv_hip_cg_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
 int spmv_hip_cg_set_x(spmv_hip_cg *c, const double *x_host)
 {
+    if (c->np > 0) {
+        for (int k = 0; k < c->np; ++k) {
+            cg_part &p = c->parts[k];
+            CGCHK(hipSetDevice(p.device));
+            if (p.rows > 0)
+                CGCHK(hipMemcpyAsync(p.x, x_host + p.r0, (size_t)p.rows * sizeof(double), hipMemcpyHostToDevice, p.stream));
+        }
+        for (int k = 0; k < c->np; ++k) {
+            CGCHK(hipSetDevice(c->parts[k].device));
+            CGCHK(hipStreamSynchronize(c->parts[k].stream));
+        }
+        return 0;
+    }
     CGCHK(hipSetDevice(c->device));
     CGCHK(hipMemcpyAsync(c->x, x_host, (size_t)c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     CGCHK(hipStreamSynchronize(c->stream));
@@ -271,6 +648,16 @@ int spmv_hip_cg_set_x(spmv_hip_cg *c, const double *x_host)
 
 int spmv_hip_cg_fill_x(spmv_hip_cg *c, double value)
 {
+    if (c->np > 0) {
+        for (int k = 0; k < c->np; ++k) {
+            cg_part &p = c->parts[k];
+            CGCHK(hipSetDevice(p.device));
+            if (p.rows > 0)
+                hipLaunchKernelGGL(k_cg_scale, dim3((p.rows + 255) / 256), dim3(256), 0, p.stream, p.x, (const double *)nullptr, value, p.rows);
+            CGCHK(hipGetLastError());
+        }
+        return 0;
+    }
     CGCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(k_cg_scale, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->x, (const double *)nullptr,
                        value, c->n);
@@ -281,9 +668,23 @@ int spmv_hip_cg_fill_x(spmv_hip_cg *c, double value)
 /* which: 0 x, 1 z, 2 p, 3 q, 4 r */
 int spmv_hip_cg_get(spmv_hip_cg *c, int which, double *host)
 {
-    double *v[] = {c->x, c->z, c->p, c->q, c->r};
     if (which < 0 || which > 4)
         return -1;
+    if (c->np > 0) {
+        for (int k = 0; k < c->np; ++k) {
+            cg_part &p = c->parts[k];
+            const double *v[] = {p.x, p.z, p.pfull + p.r0, p.q, p.r};
+            CGCHK(hipSetDevice(p.device));
+            if (p.rows > 0)
+                CGCHK(hipMemcpyAsync(host + p.r0, v[which], (size_t)p.rows * sizeof(double), hipMemcpyDeviceToHost, p.stream));
+        }
+        for (int k = 0; k < c->np; ++k) {
+            CGCHK(hipSetDevice(c->parts[k].device));
+            CGCHK(hipStreamSynchronize(c->parts[k].stream));
+        }
+        return 0;
+    }
+    double *v[] = {c->x, c->z, c->p, c->q, c->r};
     CGCHK(hipSetDevice(c->device));
     CGCHK(hipMemcpyAsync(host, v[which], (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     CGCHK(hipStreamSynchronize(c->stream));
@@ -293,6 +694,8 @@ int spmv_hip_cg_get(spmv_hip_cg *c, int which, double *host)
 /* conj_grad of cg.f:447-644: z ~= A^-1 x by cgitmax CG iterations, *rnorm = ||x - A z||. */
 int spmv_hip_cg_conj_grad(spmv_hip_cg *c, int cgitmax, double *rnorm)
 {
+    if (c->np > 0)
+        return multi_conj_grad(c, cgitmax, rnorm);
     CGCHK(hipSetDevice(c->device));
     const int n = c->n, nb = c->nb;
     hipStream_t st = c->stream;
@@ -335,6 +738,34 @@ int spmv_hip_cg_conj_grad(spmv_hip_cg *c, int cgitmax, double *rnorm)
 /* norm_temp1 = x.z, norm_temp2 = z.z   (cg.f:323-327) */
 int spmv_hip_cg_norms(spmv_hip_cg *c, double *x_dot_z, double *z_dot_z)
 {
+    if (c->np > 0) { /* per part the block partials of x.z and z.z; the host adds them part by part, in index order */
+        double *h2 = c->h_part + c->nb + c->np + 1;
+        for (int k = 0; k < c->np; ++k) {
+            cg_part &p = c->parts[k];
+            if (p.rows == 0)
+                continue;
+            CGCHK(hipSetDevice(p.device));
+            hipLaunchKernelGGL(k_cg_dot, dim3(p.nb), dim3(256), 0, p.stream, p.x, p.z, p.part[2], p.z, p.z, p.part[3], p.rows);
+            CGCHK(hipGetLastError());
+            CGCHK(hipMemcpyAsync(c->h_part + p.r0 / VB + k, p.part[2], (size_t)p.nb * sizeof(double), hipMemcpyDeviceToHost, p.stream));
+            CGCHK(hipMemcpyAsync(h2 + p.r0 / VB + k, p.part[3], (size_t)p.nb * sizeof(double), hipMemcpyDeviceToHost, p.stream));
+        }
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < c->np; ++k) {
+            cg_part &p = c->parts[k];
+            if (p.rows == 0)
+                continue;
+            CGCHK(hipSetDevice(p.device));
+            CGCHK(hipStreamSynchronize(p.stream));
+            for (int i = 0; i < p.nb; ++i) {
+                a += c->h_part[p.r0 / VB + k + i];
+                b += h2[p.r0 / VB + k + i];
+            }
+        }
+        *x_dot_z = a;
+        *z_dot_z = b;
+        return 0;
+    }
     CGCHK(hipSetDevice(c->device));
     const int nb = c->nb;
     hipLaunchKernelGGL(k_cg_dot, dim3(nb), dim3(256), 0, c->stream, c->x, c->z, c->part[2], c->z, c->z, c->part[3],
@@ -356,6 +787,16 @@ int spmv_hip_cg_norms(spmv_hip_cg *c, double *x_dot_z, double *z_dot_z)
 /* x = scale * z   (cg.f:343-345) */
 int spmv_hip_cg_x_from_z(spmv_hip_cg *c, double scale)
 {
+    if (c->np > 0) {
+        for (int k = 0; k < c->np; ++k) {
+            cg_part &p = c->parts[k];
+            CGCHK(hipSetDevice(p.device));
+            if (p.rows > 0)
+                hipLaunchKernelGGL(k_cg_scale, dim3((p.rows + 255) / 256), dim3(256), 0, p.stream, p.x, (const double *)p.z, scale, p.rows);
+            CGCHK(hipGetLastError());
+        }
+        return 0;
+    }
     CGCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(k_cg_scale, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->x, (const double *)c->z,
                        scale, c->n);

@@ -1230,6 +1230,9 @@ int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream)
     hipLaunchKernelGGL((k_tiled<T, SPMV_TILE_WPB, R, SPMV_TILE_LDS_BYTES>), dim3(t->B),                \
                        dim3(SPMV_TILE_WPB * 64), 0, st, t->wptr, t->seg, t->col,                       \
                        (const T *)t->val, (const T *)x, (T *)y, t->rows, t->cols, t->S, t->RW)
+    /* the shipped library holds the one shape the plan uses (4 register sets); 2, 6 and 8 -- the last two spill -- are tuning
+     * aids of the debug build (tuning key 5; profiles/r01_kbench11_tiled_ablation.log) */
+#ifdef SPMV_HIP_DEBUG_BUILD
 #define SPMV_LTK(T)                                                                                    \
     do {                                                                                               \
         if (g_tune_tile_k == 2)                                                                        \
@@ -1241,6 +1244,9 @@ int spmvk_tiled(const spmv_dev_tiled *t, const void *x, void *y, void *stream)
         else                                                                                           \
             SPMV_LT(T, 4);                                                                             \
     } while (0)
+#else
+#define SPMV_LTK(T) SPMV_LT(T, 4)
+#endif
     if (t->elem == 8)
         SPMV_LTK(double);
     else

@@ -485,22 +485,39 @@ int npb_cg_run(const npb_matrix *m, spmv_harness_fn spmv, int niter_override, in
     return 0;
 }
 
-/* cg.f:193-402 with conj_grad on the device (see npb_cg.h). */
-int npb_cg_run_device(const npb_matrix *m, const npb_cg_device_fns *f, int niter_override, int verbose,
+/* cg.f:193-402 with conj_grad on the device (see npb_cg.h): nparts = 0 one matrix on device 0, else row blocks */
+static int run_device(const npb_matrix *m, const npb_cg_device_fns *f, int nparts, int ndevices, int niter_override, int verbose,
                       npb_result *out)
 {
     memset(out, 0, sizeof *out);
     const int n = m->cls.na;
     const int niter = niter_override > 0 ? niter_override : m->cls.niter;
-    if (niter > NPB_MAX_ITER || m->row_begin != 0 || m->row_end != n)
+    if (niter > NPB_MAX_ITER || m->row_begin != 0 || m->row_end != n || nparts < 0 || nparts > 64)
         return -1;
     const double t_init0 = now_s();
-    void *dm = f->matrix_create(m->a, m->rowstr, m->colidx, n, 8, 0, 0, n, n);
-    if (!dm)
-        return -3;
-    void *cg = f->cg_create(dm);
+    void *dms[64] = {0};
+    void *cg = NULL;
+    int ndm = 0;
+    if (nparts == 0) {
+        dms[0] = f->matrix_create(m->a, m->rowstr, m->colidx, n, 8, 0, 0, n, n);
+        ndm = dms[0] ? 1 : 0;
+        cg = dms[0] ? f->cg_create(dms[0]) : NULL;
+    } else {
+        int bounds[65];
+        if (!f->partition_rows || !f->cg_create_multi || ndevices < 1)
+            return -1;
+        f->partition_rows(m->rowstr, n, nparts, bounds);
+        for (int k = 0; k < nparts; ++k) {
+            dms[k] = f->matrix_create(m->a, m->rowstr, m->colidx, n, 8, k % ndevices, bounds[k], bounds[k + 1], n);
+            if (!dms[k])
+                break;
+            ++ndm;
+        }
+        cg = ndm == nparts ? f->cg_create_multi(dms, nparts) : NULL;
+    }
     if (!cg) {
-        f->matrix_destroy(dm);
+        for (int k = 0; k < ndm; ++k)
+            f->matrix_destroy(dms[k]);
         return -3;
     }
     double rnorm = 0.0, zeta = 0.0, t1 = 0.0, t2 = 0.0;
@@ -531,7 +548,8 @@ int npb_cg_run_device(const npb_matrix *m, const npb_cg_device_fns *f, int niter
     }
     out->t_bench = now_s() - t0;
     f->cg_destroy(cg);
-    f->matrix_destroy(dm);
+    for (int k = 0; k < ndm; ++k)
+        f->matrix_destroy(dms[k]);
     if (rc)
         return -4;
     out->cls = m->cls.name;
@@ -550,6 +568,19 @@ int npb_cg_run_device(const npb_matrix *m, const npb_cg_device_fns *f, int niter
                     1000000.0;
     }
     return 0;
+}
+
+int npb_cg_run_device(const npb_matrix *m, const npb_cg_device_fns *f, int niter_override, int verbose, npb_result *out)
+{
+    return run_device(m, f, 0, 1, niter_override, verbose, out);
+}
+
+int npb_cg_run_device_parts(const npb_matrix *m, const npb_cg_device_fns *f, int nparts, int ndevices, int niter_override,
+                            int verbose, npb_result *out)
+{
+    if (nparts < 1)
+        return -1;
+    return run_device(m, f, nparts, ndevices, niter_override, verbose, out);
 }
 
 void npb_print_result(const npb_result *r)

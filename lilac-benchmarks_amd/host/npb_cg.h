@@ -98,9 +98,16 @@ typedef struct npb_cg_device_fns {
     int (*cg_conj_grad)(void *c, int cgitmax, double *rnorm);
     int (*cg_norms)(void *c, double *x_dot_z, double *z_dot_z);
     int (*cg_x_from_z)(void *c, double scale);
+    /* the row-partitioned step (spmv_hip_partition_rows, spmv_hip_cg_create_multi); only npb_cg_run_device_parts uses them */
+    void (*partition_rows)(const int *rowstr, int rows, int parts, int *bounds);
+    void *(*cg_create_multi)(void **parts, int nparts);
 } npb_cg_device_fns;
 int npb_cg_run_device(const npb_matrix *m, const npb_cg_device_fns *f, int niter_override, int verbose,
                       npb_result *out);
+/* The same with the matrix in `nparts` row blocks of about equal nonzeros, block k on device k % ndevices (x replicated, the
+ * scalars of conj_grad exchanged through the host, the slices of p peer to peer: csrc/spmv_cg.hip). */
+int npb_cg_run_device_parts(const npb_matrix *m, const npb_cg_device_fns *f, int nparts, int ndevices, int niter_override,
+                            int verbose, npb_result *out);
 
 /* Prints the result in the layout of NPB's print_results (common/print_results.f). */
 void npb_print_result(const npb_result *r);

@@ -38,14 +38,16 @@ class Result(ctypes.Structure):
 class DeviceFns(ctypes.Structure):
     """struct npb_cg_device_fns (host/npb_cg.h): addresses of the backend's opt-in CG entry points."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("matrix_create", "matrix_destroy", "cg_create", "cg_destroy",
-                                               "cg_fill_x", "cg_conj_grad", "cg_norms", "cg_x_from_z")]
+                                               "cg_fill_x", "cg_conj_grad", "cg_norms", "cg_x_from_z",
+                                               "partition_rows", "cg_create_multi")]
 
     @classmethod
     def from_backend(cls, be):
         names = {"matrix_create": "spmv_hip_matrix_create", "matrix_destroy": "spmv_hip_matrix_destroy",
                  "cg_create": "spmv_hip_cg_create", "cg_destroy": "spmv_hip_cg_destroy",
                  "cg_fill_x": "spmv_hip_cg_fill_x", "cg_conj_grad": "spmv_hip_cg_conj_grad",
-                 "cg_norms": "spmv_hip_cg_norms", "cg_x_from_z": "spmv_hip_cg_x_from_z"}
+                 "cg_norms": "spmv_hip_cg_norms", "cg_x_from_z": "spmv_hip_cg_x_from_z",
+                 "partition_rows": "spmv_hip_partition_rows", "cg_create_multi": "spmv_hip_cg_create_multi"}
         f = cls()
         for field, sym in names.items():
             setattr(f, field, ctypes.cast(getattr(be.lib, sym), ctypes.c_void_p).value)
@@ -69,6 +71,8 @@ def lib():
         L.npb_class_lookup.argtypes = [ctypes.c_char, ctypes.POINTER(Class)]
         L.npb_cg_run_device.argtypes = [ctypes.POINTER(CMatrix), ctypes.POINTER(DeviceFns), ctypes.c_int,
                                         ctypes.c_int, ctypes.POINTER(Result)]
+        L.npb_cg_run_device_parts.argtypes = [ctypes.POINTER(CMatrix), ctypes.POINTER(DeviceFns), ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.POINTER(Result)]
     return _lib
 
 
@@ -117,6 +121,20 @@ class NpbMatrix:
         if rc != 0:
             raise RuntimeError("npb_cg_run_device failed with %d: %s" % (rc, backend.last_error()))
         return r.as_dict()
+
+    def run_cg_device_parts(self, backend, nparts, ndevices=None, niter=0, verbose=False):
+        """The benchmark with conj_grad on the GPUs, the matrix in `nparts` row blocks (block k on device k % ndevices):
+        spmv_hip_cg_create_multi."""
+        fns = DeviceFns.from_backend(backend)
+        r = Result()
+        nd = ndevices or max(1, min(nparts, backend.device_count()))
+        rc = lib().npb_cg_run_device_parts(ctypes.byref(self.c), ctypes.byref(fns), nparts, nd, niter, 1 if verbose else 0,
+                                           ctypes.byref(r))
+        if rc != 0:
+            raise RuntimeError("npb_cg_run_device_parts failed with %d: %s" % (rc, backend.last_error()))
+        d = r.as_dict()
+        d["row_partitions"], d["devices_used"] = nparts, nd
+        return d
 
     def total_mop(self, niter=None):
         niter = niter or self.niter

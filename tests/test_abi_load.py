@@ -91,3 +91,20 @@ def test_product_never_touches_the_oracle():
                     or f in ("__init__.py",), os.path.join(base, f)
                 assert "liboracle" not in text, os.path.join(base, f)
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(base, f)
+
+
+def test_no_shipped_kernel_spills(pkg):
+    """libhip-spmv.so holds the kernels the plans use and none of them touches scratch memory -- read from
+    the gfx950 code objects' own metadata (tools/kernel_resources.py: the offload bundles inside the library, llvm-readelf
+    notes); the spilling tuning variants (k_tiled with 6 / 8 register sets) live in the debug library only."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels(pkg.lib_path())
+    assert len(ks) >= 60, len(ks)  # all five .hip files are in there
+    bad = [(k.get("name"), k.get("scratch"), k.get("vgpr_spill"), k.get("sgpr_spill")) for k in ks
+           if k.get("scratch", 0) or k.get("vgpr_spill", 0) or k.get("sgpr_spill", 0)]
+    assert not bad, bad
+    assert not [k["name"] for k in ks if k.get("agpr", 0)]  # no MFMA accumulators anywhere: this is a gather, not a contraction
+    dbg = kernel_resources.kernels(pkg.lib_path("libhip-spmv-debug.so"))
+    assert len(dbg) > len(ks)  # the instrumented twins and the tuning variants are there instead
