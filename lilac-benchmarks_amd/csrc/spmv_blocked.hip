@@ -558,10 +558,16 @@ template <typename T> static void launch_blocked(const spmv_dev_blocked *d, cons
 extern "C" int spmvk_blocked(const spmv_dev_blocked *d, const void *x, void *y, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (d->rows <= 0)
-        return 0;
+    if (d->rows <= 0) { /* a plan without its layout (a refresh that failed half-way): never a silent stale y */
+        spmv_set_error("BLOCKED: no layout behind the plan");
+        return -1;
+    }
     if (d->W != (d->elem == 8 ? BlkGeom<double>::W : BlkGeom<float>::W)) { /* the layout was planned for another kernel */
         spmv_set_error("BLOCKED: layout planned for %d elements of x in LDS", d->W);
+        return -1;
+    }
+    if (d->RB < 1024 || d->RB > 2560 || d->RB % 256) { /* the bin sizes phase 2 is instantiated for (launch_blocked's switch) */
+        spmv_set_error("BLOCKED: no kernel for bins of %d rows", d->RB);
         return -1;
     }
     if (d->elem == 8)
