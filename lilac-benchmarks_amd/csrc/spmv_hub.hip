@@ -46,8 +46,8 @@ template <typename T> struct HubGeom {
     static constexpr int E = Vec16<T>::E;          /* entries per lane per sub-step: one 16-byte value load         */
     static constexpr int SUB = 64 * E;             /* entries per sub-step: 128 / 256                               */
     static constexpr int NSUB = CH / SUB;          /* sub-steps per chunk: 8 / 4                                    */
-    static constexpr int H = 2;                    /* sub-steps per pipeline stage (their loads travel together)    */
-    static constexpr int NST = NSUB / H;           /* stages per chunk: 4 / 2                                       */
+    static constexpr int H = 4;                    /* sub-steps per pipeline stage (their loads travel together)    */
+    static constexpr int NST = NSUB / H;           /* stages per chunk: 2 / 1                                       */
     static constexpr int RING = 2 * SUB;           /* row sums a wave parks before they leave: 2 KB per wave        */
     static constexpr int SLOTS = sizeof(T) == 8 ? 16352 : 32736; /* = spmv_hub_lds_slots: table + rings + ticket <= 160 KB */
     static_assert(NSUB % H == 0 && NST >= 1, "a chunk is a whole number of stages");
@@ -57,13 +57,6 @@ template <typename T> struct HubGeom {
 template <typename T> struct HubStage {
     typename Vec16<T>::idx_t c[HubGeom<T>::H];
     typename Vec16<T>::val_t v[HubGeom<T>::H];
-};
-
-/* where a stage lies: chunk, stage of the chunk, and -- loaded when the chunk was drawn, a stage or two before it is needed --
- * the number of row ends in front of the chunk */
-struct HubPos {
-    int c, st, rank;
-    bool ok;
 };
 
 template <typename T>
@@ -79,24 +72,6 @@ __device__ __forceinline__ void hub_load(HubStage<T> &s, const unsigned int *__r
         s.c[k] = *reinterpret_cast<const IT *>(col2 + base + k * G::SUB);
         s.v[k] = *reinterpret_cast<const VT *>(val + base + k * G::SUB);
     }
-}
-
-/* the entries of a stage that are not in the LDS table fetch their x from memory: the dense second-tier table (cache hits) or
- * x itself.  No branch around the loads -- an LDS entry reads x[0], one address for all such lanes -- so that the number of
- * loads in flight is the same on every path and the waits stay exact. */
-template <typename T>
-__device__ __forceinline__ void hub_gather(T (&xg)[HubGeom<T>::H][HubGeom<T>::E], const HubStage<T> &s, const T *__restrict__ x,
-                                           const T *__restrict__ xh)
-{
-#pragma unroll
-    for (int k = 0; k < HubGeom<T>::H; ++k)
-#pragma unroll
-        for (int i = 0; i < HubGeom<T>::E; ++i) {
-            const unsigned int cc = (unsigned int)s.c[k][i];
-            const T *base = (cc & TBL) ? xh : x;
-            const unsigned int idx = (cc & HUB) ? 0u : (cc & IDX);
-            xg[k][i] = base[idx];
-        }
 }
 
 /* Every product is rounded before it is added (no contraction): the result is a function of the layout, addition by
@@ -129,41 +104,22 @@ __global__ void __launch_bounds__(NT_WG) k_hub(const unsigned int *__restrict__ 
         s_ticket = 0u;
     __syncthreads();
 
-    /* the stage behind p: the next stage of the same chunk, or stage 0 of the next chunk the wave draws (with the chunk's rank
-     * on its way at once: by the time the stage is computed it has long arrived) */
-    auto advance = [&](const HubPos p) -> HubPos {
-        HubPos r = p;
-        if (!p.ok)
-            return r;
-        if (p.st + 1 < G::NST) {
-            r.st = p.st + 1;
-            return r;
-        }
+    auto draw = [&]() -> int {
         unsigned int t = 0u;
         if (lane == 0)
             t = __hip_atomic_fetch_add(&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        r.c = c0 + (int)__builtin_amdgcn_readfirstlane((int)t);
-        r.st = 0;
-        r.ok = r.c < c1;
-        r.rank = rank0[r.ok ? r.c : p.c];
-        return r;
+        return c0 + (int)__builtin_amdgcn_readfirstlane((int)t);
     };
 
-    HubPos pc{c0 - 1, G::NST - 1, 0, true};
-    pc = advance(pc); /* the wave's first chunk */
-    if (!pc.ok)
+    int c = draw();
+    if (c >= c1)
         return;
-    /* three stages in registers: cur (being summed; its gathers were issued a stage ago), nxt (its stream loads have arrived,
-     * its gathers are issued now), nn (its stream loads are issued now) */
-    HubStage<T> cur, nxt, nn;
-    T xg[H][E], xgn[H][E];
-    hub_load<T>(cur, col2, val, pc.c, pc.st, lane);
-    HubPos pn = advance(pc), pnn;
-    hub_load<T>(nxt, col2, val, pn.ok ? pn.c : pc.c, pn.ok ? pn.st : pc.st, lane);
-    hub_gather<T>(xg, cur, x, xh);
+    int st = 0;
+    HubStage<T> cur;
+    hub_load<T>(cur, col2, val, c, 0, lane);
 
     /* per-chunk state of the wave */
-    int rank_base = __builtin_amdgcn_readfirstlane(pc.rank);
+    int rank_base = __builtin_amdgcn_readfirstlane(rank0[c]);
     unsigned int row = 0, flushed = 0; /* row ends met in this chunk; how many of them have left the ring (a multiple of 64) */
     T carry = (T)0;                    /* open sum of the row that spans the sub-step boundary */
     int rnext = IDENT ? 0 : nzrow[rank_base + lane];
@@ -180,18 +136,31 @@ __global__ void __launch_bounds__(NT_WG) k_hub(const unsigned int *__restrict__ 
     };
 
     for (;;) {
-        /* ---- two stages ahead: the stream; one stage ahead: the gathers (no branch: past the end the last stage again, never used) ---- */
-        pnn = advance(pn);
-        hub_load<T>(nn, col2, val, pnn.ok ? pnn.c : pc.c, pnn.ok ? pnn.st : pc.st, lane);
-        hub_gather<T>(xgn, nxt, x, xh);
-        /* ---- x of this stage: gathered a stage ago, or the LDS table ---- */
+        /* ---- x for the stage: the entries that are not hubs gather from memory (issued first), hubs read the table ---- */
         T xv[H][E];
 #pragma unroll
         for (int k = 0; k < H; ++k)
 #pragma unroll
             for (int i = 0; i < E; ++i) {
                 const unsigned int cc = (unsigned int)cur.c[k][i];
-                xv[k][i] = xg[k][i];
+                xv[k][i] = (T)0;
+                if (!(cc & HUB)) /* tier 1: the dense table in memory (cache hits); else x itself */
+                    xv[k][i] = ((cc & TBL) ? xh : x)[cc & IDX];
+            }
+        /* ---- the next stage's stream loads: no branch around them (past the end: this chunk again, never used) ---- */
+        int nc = c, nst = st + 1;
+        if (nst == G::NST) {
+            nc = draw();
+            nst = 0;
+        }
+        const bool more = nc < c1;
+        HubStage<T> nxt;
+        hub_load<T>(nxt, col2, val, more ? nc : c, more ? nst : st, lane);
+#pragma unroll
+        for (int k = 0; k < H; ++k)
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const unsigned int cc = (unsigned int)cur.c[k][i];
                 if (cc & HUB)
                     xv[k][i] = s_x[cc & IDX];
             }
@@ -258,27 +227,23 @@ __global__ void __launch_bounds__(NT_WG) k_hub(const unsigned int *__restrict__ 
             __builtin_amdgcn_wave_barrier();
         }
 
-        if (pc.st == G::NST - 1) { /* the chunk is done: its last < 64 rows, and what it leaves open */
+        if (st == G::NST - 1) { /* the chunk is done: its last < 64 rows, and what it leaves open */
             flush(row);
             __builtin_amdgcn_wave_barrier();
             if (lane == 0)
-                carry_out[pc.c] = carry;
+                carry_out[c] = carry;
         }
-        if (!pn.ok)
+        if (!more)
             break;
-        if (pn.st == 0) { /* a new chunk */
-            rank_base = __builtin_amdgcn_readfirstlane(pn.rank);
+        if (nst == 0) {
+            c = nc;
+            rank_base = __builtin_amdgcn_readfirstlane(rank0[c]);
             row = 0, flushed = 0, carry = (T)0;
             if (!IDENT)
                 rnext = nzrow[rank_base + lane];
         }
-        pc = pn, pn = pnn;
-        cur = nxt, nxt = nn;
-#pragma unroll
-        for (int k = 0; k < H; ++k)
-#pragma unroll
-            for (int i = 0; i < E; ++i)
-                xg[k][i] = xgn[k][i];
+        st = nst;
+        cur = nxt;
     }
 }
 
