@@ -33,8 +33,9 @@ enum {
                                /* of x in LDS at a time, row sums carried in registers across the  */
                                /* group, one partial sum per (group, row), added in group order     */
     SPMV_HIP_PLAN_HUB = 8,     /* the CSR stream in fixed chunks, segmented wave scan, the most referenced ("hub") columns   */
-                               /* of x in LDS: for power-law graphs (bfs, pagerank), where a few thousand columns take most */
-                               /* of the gathers; values are read from the CSR copy itself                                  */
+                               /* of x in LDS and the next 262 144 in a dense table in memory: for power-law graphs (bfs,   */
+                               /* pagerank), where a few thousand columns take most of the gathers; values are read from    */
+                               /* the CSR copy itself (a value refresh costs this plan nothing)                             */
     SPMV_HIP_PLAN_BLOCKED = 7  /* two phases over (column stripe, row bin) cells: a workgroup keeps a    */
                                /* stripe of x in LDS and writes the PRODUCTS binned by row; one wave per */
                                /* bin adds them in LDS.  No gathers from memory: for short rows with     */
@@ -103,8 +104,11 @@ int spmv_hip_matrix_info(const spmv_hip_matrix *m, spmv_hip_info *out);
 /*
  * New values for the same sparsity pattern: copies the block's share of `a` (the array spmv_hip_matrix_create was given,
  * same base pointer, same layout) into the device copy that exists -- no allocation, no validation, the plan stays.  A
- * re-laid-out plan (STRIPED / TILED) packs its second copy again, from `colidx` when given (the caller's array, as at
- * creation) or from the device's CSR copy when NULL.  0 on success.
+ * re-laid-out plan packs its second copy again: STRIPED / TILED in place, from `colidx` when given (the caller's array, as
+ * at creation) or from the device's CSR copy when NULL; BLOCKED frees its layout and builds it anew on the device (count,
+ * plan, scatter: allocations, and a device-to-host copy of one counter per cell -- about the cost of its first build);
+ * HUB holds no values and does nothing.  0 on success; after a failure (-1: the error string says why) the matrix is left on
+ * the CSR kernels, never on a plan without its layout.
  */
 int spmv_hip_matrix_refresh_values(spmv_hip_matrix *m, const void *a, const int *colidx);
 /* Force a plan (tests, benchmarks).  plan_param: lanes for VECTOR (1,2,4,..,64), 0 = default. */

@@ -765,12 +765,12 @@ static int ensure_hub(spmv_hip_matrix *m, bool auto_choice)
     return 0;
 }
 
-/* AUTO's last question, asked when the CSR kernel would otherwise serve a matrix that is large enough to care: do a few
+/* AUTO's last question, asked when the CSR kernel would otherwise serve a matrix that is large enough to care (2 M nonzeros, 1 MB of x): do a few
  * thousand columns take a good share of the gathers?  (R-MAT 2^20: STREAM 107 us, HUB see profiles/r04_hub_*.log.)  The
  * builder counts the references per column and declines when they do not. */
 static bool hub_nominated(const spmv_hip_matrix *m)
 {
-    return m->nnz >= 2000000 && (int64_t)m->cols * m->elem >= (2ll << 20) && m->cols < (1 << 29);
+    return m->nnz >= 2000000 && (int64_t)m->cols * m->elem >= (1ll << 20) && m->cols < (1 << 29);
 }
 
 spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const int *colidx, int rows,

@@ -394,7 +394,13 @@ extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host
         goto out;
     base1 = (g.K + 1 + 15) / 16 * 16; /* tier 1 begins on a 64- / 128-byte boundary behind tier 0 and its zero */
     n_slots = (size_t)base1 + (size_t)g.K2;
-    if (auto_choice && 100 * (g.covered + g.covered2) < (int64_t)g_hub_min_cover.load(std::memory_order_relaxed) * nnz) {
+    /* the automatic choice wants real hubs: the share of the entries that the LDS table alone takes.  The second tier does not
+     * count -- 262 144 columns cover half of ANY matrix with half a million columns, and on uniformly scattered or banded columns
+     * the plan then loses to the CSR kernels by 13-63 % (profiles/r04_dispatch_audit_before_the_criterion.log) */
+    /* ... and hubs means: referenced four times as often as the average column that is referenced at all (the K most popular of
+     * uniformly used columns cover K / columns of the entries and are no hubs, however few the columns) */
+    if (auto_choice && (100 * g.covered < (int64_t)g_hub_min_cover.load(std::memory_order_relaxed) * nnz ||
+                        (double)g.covered * (double)g.cols_used < 4.0 * (double)g.K * (double)nnz)) {
         rc = -2; /* no hubs to speak of: the CSR kernel gathers as well */
         goto out;
     }

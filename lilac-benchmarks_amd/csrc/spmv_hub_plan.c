@@ -117,6 +117,9 @@ int spmv_hub_select(const int *colcount, int cols, int kmax, int kmax2, int min_
         }
     }
     g->K = (int)K, g->K2 = (int)K2;
+    g->cols_used = 0;
+    for (int c = 0; c < cols; ++c)
+        g->cols_used += colcount[c] > 0;
     free(tier);
     return 0;
 }

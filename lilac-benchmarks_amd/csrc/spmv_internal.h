@@ -275,6 +275,7 @@ typedef struct spmv_hub_plan {
     int K2;           /* tier-1 hub columns: the dense table in memory                                            */
     int64_t covered;  /* entries whose column is a tier-0 hub                                                      */
     int64_t covered2; /* entries whose column is a tier-1 hub                                                      */
+    int cols_used;    /* columns referenced at all                                                                 */
     int CH, n_chunks; /* entries per chunk, chunks                                                                 */
     int n_nzrows, n_empty, n_fix, identity;
     int *hubcol;      /* [K + K2] 0-based columns, ascending within each tier                                      */

@@ -1071,7 +1071,7 @@ int dispatch_vector(const spmv_dev_csr *m, int lanes, const int *row_list, int n
 
 /* the two instantiated shapes of k_striped: 16 waves over a 128-KiB stripe (one workgroup per CU) and 8 waves over a
  * 64-KiB stripe (two per CU, which run out of step: one streams while the other stages x or waits at its barrier) */
-template <typename T, int WPB, int XB, int R, bool DIAG>
+template <typename T, int WPB, int XB, int R, bool DIAG, int NACC = SPMV_STRIPE_NACC>
 void launch_striped(const spmv_dev_striped *t, const void *x, void *y, hipStream_t st, const void *dotv,
                            void *dot_part, int grid, int nwg, int per, int abl)
 {
@@ -1079,11 +1079,11 @@ void launch_striped(const spmv_dev_striped *t, const void *x, void *y, hipStream
     const long long stream = (long long)t->n_packed * (long long)(sizeof(T) + 2);
     const bool nt = g_tune_striped_nt == 1 || (g_tune_striped_nt == 0 && stream > SPMV_STRIPE_NT_BYTES);
     if (nt)
-        hipLaunchKernelGGL((k_striped<T, WPB, R, XB, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC, DIAG, true>), dim3(grid), dim3(WPB * 64), 0,
+        hipLaunchKernelGGL((k_striped<T, WPB, R, XB, SPMV_STRIPE_EPL, NACC, DIAG, true>), dim3(grid), dim3(WPB * 64), 0,
                            st, t->tptr, t->rrow, t->wgd, t->col, (const T *)t->val, (const T *)x, (T *)y, (T *)t->partial,
                            (const T *)dotv, (T *)dot_part, t->rows, t->cols, t->NG, t->GM, t->W, nwg, per, abl);
     else
-        hipLaunchKernelGGL((k_striped<T, WPB, R, XB, SPMV_STRIPE_EPL, SPMV_STRIPE_NACC, DIAG, false>), dim3(grid), dim3(WPB * 64), 0,
+        hipLaunchKernelGGL((k_striped<T, WPB, R, XB, SPMV_STRIPE_EPL, NACC, DIAG, false>), dim3(grid), dim3(WPB * 64), 0,
                            st, t->tptr, t->rrow, t->wgd, t->col, (const T *)t->val, (const T *)x, (T *)y, (T *)t->partial,
                            (const T *)dotv, (T *)dot_part, t->rows, t->cols, t->NG, t->GM, t->W, nwg, per, abl);
 }
@@ -1093,6 +1093,17 @@ void launch_striped_shape(const spmv_dev_striped *t, const void *x, void *y, hip
                                  void *dot_part, int grid, int nwg, int per)
 {
 #ifdef SPMV_HIP_DEBUG_BUILD
+    /* experiments of round 4 (profiles/r04_classC_where_the_step_goes.md): fewer accumulators for layouts whose wave ranges are
+     * short, which frees registers for a deeper ring -- clean instantiations, no ablation code in them.  Tuning key 5:
+     * 12 = 2 sets, 4 accumulators (the control); 14 = 4 sets, 4 accumulators; 13 = 3 sets, 8 accumulators */
+    if (g_tune_abl == 0 && g_tune_tile_k >= 12 && g_tune_tile_k <= 14) {
+        if (g_tune_tile_k == 12 && t->wave_rows <= 256)
+            return launch_striped<T, WPB, XB, 2, false, 4>(t, x, y, st, dotv, dot_part, grid, nwg, per, 0);
+        if (g_tune_tile_k == 14 && t->wave_rows <= 256)
+            return launch_striped<T, WPB, XB, 4, false, 4>(t, x, y, st, dotv, dot_part, grid, nwg, per, 0);
+        if (g_tune_tile_k == 13 && t->wave_rows <= 512)
+            return launch_striped<T, WPB, XB, 3, false, 8>(t, x, y, st, dotv, dot_part, grid, nwg, per, 0);
+    }
     if (g_tune_abl != 0 || g_tune_tile_k == 3 || g_tune_tile_k == 4) { /* the instrumented twin, on request only */
         if (g_tune_tile_k == 4)
             launch_striped<T, WPB, XB, 4, true>(t, x, y, st, dotv, dot_part, grid, nwg, per, g_tune_abl);
@@ -1118,7 +1129,7 @@ void spmvk_set_tuning(int key, int value)
         g_tune_xcd = value;
     else if (key == 1)
         g_tune_nt = value;
-    else if (key == 5 && value >= 0 && value <= 8)
+    else if (key == 5 && value >= 0 && value <= 14)
         g_tune_tile_k = value;
     else if (key == 20 && value >= 0 && value <= 2)
         g_tune_striped_nt = value;

@@ -31,7 +31,7 @@ LANES = np.arange(64)
 
 
 class HubPlan(ctypes.Structure):
-    _fields_ = [("K", ctypes.c_int), ("K2", ctypes.c_int), ("covered", ctypes.c_int64), ("covered2", ctypes.c_int64),
+    _fields_ = [("K", ctypes.c_int), ("K2", ctypes.c_int), ("covered", ctypes.c_int64), ("covered2", ctypes.c_int64), ("cols_used", ctypes.c_int),
                 ("CH", ctypes.c_int), ("n_chunks", ctypes.c_int),
                 ("n_nzrows", ctypes.c_int), ("n_empty", ctypes.c_int), ("n_fix", ctypes.c_int), ("identity", ctypes.c_int),
                 ("hubcol", ctypes.POINTER(ctypes.c_int)), ("slot_of", ctypes.POINTER(ctypes.c_int)),
@@ -55,7 +55,7 @@ def plan(lib, rs, ci, cols, kmax, ch=1024, min_count=2, kmax2=0):
     assert lib.spmv_hub_rows(rsc.ctypes.data, int(rsc[0]), rsc.size - 1, ch, ctypes.byref(g)) == 0
     arr = lambda p, n: np.ctypeslib.as_array(p, (n,)).astype(np.int64).copy() if n else np.zeros(0, np.int64)  # noqa: E731
     both = arr(g.hubcol, g.K + g.K2)
-    out = dict(K=g.K, K2=g.K2, covered=int(g.covered), covered2=int(g.covered2), CH=g.CH, n_chunks=g.n_chunks, identity=g.identity,
+    out = dict(K=g.K, K2=g.K2, covered=int(g.covered), covered2=int(g.covered2), cols_used=g.cols_used, CH=g.CH, n_chunks=g.n_chunks, identity=g.identity,
                hubcol=both[:g.K], hubcol2=both[g.K:],
                slot_of=arr(g.slot_of, cols), rank0=arr(g.rank0, g.n_chunks + 1), nzrow=arr(g.nzrow, g.n_nzrows),
                erow=arr(g.erow, g.n_empty), fix=arr(g.fix, 3 * g.n_fix).reshape(-1, 3))

@@ -51,6 +51,7 @@ def test_hub_plan_and_its_restatement(planlib, oracle, name, dtype):
             elif rest.size:
                 assert rest.max() < 2  # room left: every column referenced twice or more is in
         assert p["covered"] == int(cnt[p["hubcol"]].sum())
+        assert p["cols_used"] == int(np.count_nonzero(cnt))
         # ---- tier 1 (the dense table in memory): the kmax2 most referenced of the REST, slots behind tier 0's
         K2, h2 = p["K2"], p["hubcol2"]
         assert K2 <= kmax2 and np.all(np.diff(h2) > 0) and not np.intersect1d(h2, p["hubcol"]).size

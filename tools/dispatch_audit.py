@@ -18,7 +18,7 @@ def main():
     pkg = pkgload.load_package()
     be = pkg.Backend()
     cand = [("striped", pkg.PLAN_STRIPED, 0), ("stream", pkg.PLAN_STREAM, 0), ("vec16", pkg.PLAN_VECTOR, 16),
-            ("vec64", pkg.PLAN_VECTOR, 64), ("vec4", pkg.PLAN_VECTOR, 4), ("blocked", pkg.PLAN_BLOCKED, 0)]
+            ("vec64", pkg.PLAN_VECTOR, 64), ("vec4", pkg.PLAN_VECTOR, 4), ("blocked", pkg.PLAN_BLOCKED, 0), ("hub", pkg.PLAN_HUB, 0)]
     print("%8s %6s %9s | %-8s %8s | best %-8s %8s | %s" % ("rows", "mean", "nnz", "auto", "us", "plan", "us", "all"))
     worst = []
     for rows in (2000, 8000, 32000, 128000, 512000, 2000000):
@@ -86,7 +86,7 @@ def main():
     for rows, scale in ((40000, 30.0), (300000, 8.0)):
         lens = np.minimum((rng.pareto(1.3, rows) * scale).astype(np.int64), rows // 2)
         extra.append(("pareto %d" % rows,) + matgen.csr_from_lengths(rng, [int(v) for v in lens], rows, dtype))
-    for sc in (15, 17, 19, 21):
+    for sc in (15, 17, 19, 20, 21):
         extra.append(("rmat%d" % sc,) + matgen.rmat_graph(20, sc, 16, dtype, values="normal"))
     # SparseBench-like: short rows, uniformly scattered columns, x from 8 to 33 MB (BLOCKED's ground from 16 MB on)
     for size in (100, 120, 128, 140, 160):
