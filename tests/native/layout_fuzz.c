@@ -142,9 +142,47 @@ int main(int argc, char **argv)
                 free(cnt);
             }
         }
+        /* HUB's host side (spmv_hub_plan.c): the two tiers of hub columns from one count per column, then the chunks */
+        {
+            int *cnt = (int *)calloc((size_t)cols, sizeof(int));
+            if (!cnt)
+                return 1;
+            for (int j = first - 1; j < first - 1 + (int)nnz; ++j)
+                cnt[colidx[j] - 1]++;
+            const int ksel[] = {0, 1, 7, 300, 16352, 32736}, k2sel[] = {0, 0, 5, 4000, 262144};
+            const int kmax = ksel[rnd() % 6], kmax2 = k2sel[rnd() % 5], ch = (rnd() & 1) ? 1024 : 64;
+            spmv_hub_plan g;
+            memset(&g, 0, sizeof g);
+            rc = spmv_hub_select(cnt, cols, kmax, kmax2, 1 + (int)(rnd() % 3), &g);
+            if (rc == 0)
+                rc = spmv_hub_rows(rowstr, rowstr[0], rows, ch, &g);
+            if (rc == 0) {
+                int64_t cov = 0;
+                int bad = g.K > kmax || g.K2 > kmax2 || g.n_chunks != (int)((nnz + ch - 1) / ch) || g.rank0[g.n_chunks] != g.n_nzrows ||
+                          g.n_nzrows + g.n_empty != rows;
+                for (int k = 0; k < g.K + g.K2 && !bad; ++k) {
+                    bad = g.hubcol[k] < 0 || g.hubcol[k] >= cols || g.slot_of[g.hubcol[k]] != k;
+                    cov += cnt[g.hubcol[k]];
+                }
+                for (int c = 0; c + 1 <= g.n_chunks && !bad; ++c)
+                    bad = g.rank0[c] > g.rank0[c + 1];
+                for (int k = 0; k < g.n_fix && !bad; ++k)
+                    bad = g.fix[3 * k + 1] >= g.fix[3 * k + 2] || g.fix[3 * k + 2] >= g.n_chunks || g.fix[3 * k] < 0 || g.fix[3 * k] >= rows;
+                if (bad || cov != g.covered + g.covered2) {
+                    fprintf(stderr, "case %d: inconsistent HUB plan\n", t);
+                    return 1;
+                }
+                built[1]++;
+            } else if (rc != -3) {
+                fprintf(stderr, "case %d: HUB plan rc=%d\n", t, rc);
+                return 1;
+            }
+            spmv_hub_plan_free(&g);
+            free(cnt);
+        }
         free(rowstr), free(colidx), free(a);
     }
-    printf("layout_fuzz: %d cases; striped %ld built / %ld declined; tiled %ld / %ld; blocked plan %ld / %ld\n", cases, built[0],
-           declined[0], built[2], declined[2], built[3], declined[3]);
+    printf("layout_fuzz: %d cases; striped %ld built / %ld declined; tiled %ld / %ld; blocked plan %ld / %ld; hub plan %ld\n", cases, built[0],
+           declined[0], built[2], declined[2], built[3], declined[3], built[1]);
     return 0;
 }

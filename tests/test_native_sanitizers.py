@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lilac-benchmarks_amd", "csrc")
 SOURCES = [os.path.join(ROOT, "tests", "native", "layout_fuzz.c")] + [
-    os.path.join(CSRC, f) for f in ("spmv_plan.c", "spmv_striped.c", "spmv_tiled.c", "spmv_blocked_plan.c")]
+    os.path.join(CSRC, f) for f in ("spmv_plan.c", "spmv_striped.c", "spmv_tiled.c", "spmv_blocked_plan.c", "spmv_hub_plan.c")]
 
 
 @pytest.mark.parametrize("san,cases", [("address,undefined", "250"), ("thread", "120")])
