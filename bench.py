@@ -284,6 +284,7 @@ def main():
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     n_gpus = args.gpus if inproc else world
     dist = None
+    wait_group = None
     # rehearsal aid: BENCH_DIST_BACKEND=gloo lets several ranks share the one GPU of a test box
     # (RCCL refuses two ranks on one device); the driver's real runs use nccl = RCCL, one GPU per rank
     backend_name = os.environ.get("BENCH_DIST_BACKEND", "nccl")
@@ -295,6 +296,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend_name)
+        # the ranks that only WAIT while rank 0 runs the one-process NPB legs on all GPUs do so on the CPU: an RCCL barrier is a
+        # kernel spinning on every GPU, and those GPUs are the ones rank 0's row blocks run on
+        wait_group = dist.new_group(backend="gloo") if backend_name == "nccl" else None
 
     pkg = pkgload.load_package()
     if not os.path.exists(pkg.lib_path()):
@@ -605,7 +609,7 @@ def main():
                 be.release()
             mfull.close()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=wait_group) if wait_group is not None else dist.barrier()
 
     if rank == 0 and n_gpus == 1 and not args.no_npb:
         be.reset_stats()

@@ -928,6 +928,18 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
             FAIL();
         }
     }
+    /* a power-law graph is nominated for BLOCKED by its size alone and declined by BLOCKED's builder after a count kernel of
+     * 2-4.5 ms (R-MAT 2^20: a crowded cell); its rows say what it is -- the longest 64 times the mean -- so HUB is asked first
+     * there, and BLOCKED only when HUB's builder finds no hubs */
+    if (m->plan == SPMV_HIP_PLAN_BLOCKED && g_relayout && hub_nominated(m) && (double)m->st.max_len > 64.0 * m->st.mean_len) {
+        int rc = ensure_hub(m, true);
+        if (rc == 0) {
+            m->plan = SPMV_HIP_PLAN_HUB;
+            m->param = m->dh.K;
+        } else if (rc != -2 && rc != -3) {
+            FAIL();
+        }
+    }
     if (m->plan == SPMV_HIP_PLAN_BLOCKED) {
         int rc = ensure_blocked(m, true);
         if (rc == -2 || rc == -3) {
@@ -939,7 +951,7 @@ spmv_hip_matrix *spmv_hip_matrix_create(const void *a, const int *rowstr, const 
             m->param = m->db.wcols;
         }
     }
-    if (m->plan == SPMV_HIP_PLAN_STREAM && g_relayout && hub_nominated(m)) {
+    if (m->plan == SPMV_HIP_PLAN_STREAM && g_relayout && hub_nominated(m) && !m->have_hub && m->hub_rc == 0) {
         int rc = ensure_hub(m, true);
         if (rc == 0) {
             m->plan = SPMV_HIP_PLAN_HUB;
@@ -1015,6 +1027,14 @@ int spmv_hip_matrix_set_plan(spmv_hip_matrix *m, int plan, int plan_param)
                 return -1;
             m->plan = SPMV_HIP_PLAN_STREAM;
             m->param = SPMV_STREAM_CAP;
+        }
+        if (m->plan == SPMV_HIP_PLAN_BLOCKED && hub_nominated(m) && (double)m->st.max_len > 64.0 * m->st.mean_len) { /* as at creation */
+            if (ensure_hub(m, true) == 0) {
+                m->plan = SPMV_HIP_PLAN_HUB;
+                m->param = m->dh.K;
+            } else if (m->hub_rc != -2 && m->hub_rc != -3) {
+                return -1;
+            }
         }
         if (m->plan == SPMV_HIP_PLAN_BLOCKED) {
             if (ensure_blocked(m, true)) {
