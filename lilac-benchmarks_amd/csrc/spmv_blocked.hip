@@ -68,7 +68,7 @@ template <typename T> struct BlkGeom {
 /* workgroup q: stripe wg[3q], windows [wg[3q+1], wg[3q+2]) of the phase-1 stream.  Inside a window the values lie
  * lane-interleaved in 16-byte units (entry i of lane l at (i / E) * 64 E + l E + i % E, as in STRIPED) so that every load
  * is a dense 1-KiB wave access; the columns are linear (8 bytes per lane). */
-template <typename T, int U>
+template <typename T, int U, int ABL = 0>
 __global__ void __launch_bounds__(BB_P1_WAVES * 64) k_blk_products(const int *__restrict__ wg, const T *__restrict__ val,
                                                                    const unsigned short *__restrict__ col,
                                                                    const unsigned int *__restrict__ dest4,
@@ -95,7 +95,10 @@ __global__ void __launch_bounds__(BB_P1_WAVES * 64) k_blk_products(const int *__
         for (int j = 0; j < NV; ++j)
             v[u][j] = ld<VT, true>(reinterpret_cast<const VT *>(val + base + (size_t)(j * 64 * E)) + lane);
         c[u] = ld<u32x2, true>(reinterpret_cast<const u32x2 *>(col + base) + lane);
-        d[u] = __builtin_nontemporal_load(dest4 + base / 4 + lane);
+        if (ABL & 1) /* timing only (debug build): no destination stream, the products written where they were read */
+            d[u] = (unsigned int)(base / 4) + (unsigned int)lane;
+        else
+            d[u] = __builtin_nontemporal_load(dest4 + base / 4 + lane);
     };
     /* the first U windows are on their way while x is staged */
 #pragma unroll
@@ -197,7 +200,7 @@ __device__ __forceinline__ void add_runs(double *__restrict__ sy, const unsigned
  * bin that holds more than its share (dense rows), a run of its stripes; then ps[i] >= 0 names the slot of the piece's
  * partial sums and k_blk_join adds a bin's slots in order.  The stream is linear: lane l takes the products
  * j * 64 E + l E .. + E - 1 of a window with its j-th 16-byte load */
-template <typename T, int U, int RB, bool RUNS>
+template <typename T, int U, int RB, bool RUNS, int ABL = 0>
 __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ pw, const int *__restrict__ pb,
                                                   const int *__restrict__ ps, const T *__restrict__ prod,
                                                   const unsigned short *__restrict__ lrow, int rows, int npieces,
@@ -228,7 +231,13 @@ __global__ void __launch_bounds__(256) k_blk_bins(const int *__restrict__ pw, co
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 v[u][j] = reinterpret_cast<const VT *>(prod + base + (size_t)(j * 64 * E))[lane]; /* written a moment ago: may still be cached */
-                r[u][j] = __builtin_nontemporal_load(reinterpret_cast<const rows_t *>(lrow + base + (size_t)(j * 64 * E)) + lane);
+                if (ABL & 2) { /* timing only (debug build): no row stream, every lane a row of its own */
+#pragma unroll
+                    for (int i = 0; i < E; ++i)
+                        r[u][j][i] = (unsigned short)((kk * 61 + j * 64 * E + lane * E + i) % RB);
+                } else {
+                    r[u][j] = __builtin_nontemporal_load(reinterpret_cast<const rows_t *>(lrow + base + (size_t)(j * 64 * E)) + lane);
+                }
             }
         };
 #pragma unroll
@@ -526,11 +535,34 @@ out:
 /* U = 2 windows in flight per wave in both phases: 1 to 8 differ by less than the boxes do (SparseBench 170^3: 160-164 us with 2,
  * 165-170 with 4, 180 with one window in phase 2; profiles/r03_blocked_prefetch_depth.log): 16 and 8 waves per CU hide the
  * latency, the memory system is what both phases wait for */
+#ifdef SPMV_HIP_DEBUG_BUILD
+static std::atomic<int> g_blk_abl{0}; /* timing-only ablations (tuning key 26): 1 phase 1 without dest4, 2 phase 2 without lrow */
+extern "C" void spmvk_blocked_set_abl(int v) { g_blk_abl.store(v & 3, std::memory_order_relaxed); }
+#endif
+
 template <typename T> static void launch_blocked(const spmv_dev_blocked *d, const void *x, void *y, hipStream_t st)
 {
+    const dim3 g2((d->n_pieces + 3) / 4);
+#ifdef SPMV_HIP_DEBUG_BUILD
+    const int abl = g_blk_abl.load(std::memory_order_relaxed);
+    if (abl && d->RB == 2560 && !d->runs && !d->n_join) { /* the byte-budget probes: SparseBench-like layouts only; results are wrong */
+        if (abl & 1)
+            hipLaunchKernelGGL((k_blk_products<T, 2, 1>), dim3(d->n_wg), dim3(BB_P1_WAVES * 64), 0, st, d->wg, (const T *)d->val1, d->col1,
+                               d->dest4, (const T *)x, d->cols, d->wcols, (T *)d->prod);
+        else
+            hipLaunchKernelGGL((k_blk_products<T, 2>), dim3(d->n_wg), dim3(BB_P1_WAVES * 64), 0, st, d->wg, (const T *)d->val1, d->col1,
+                               d->dest4, (const T *)x, d->cols, d->wcols, (T *)d->prod);
+        if (abl & 2)
+            hipLaunchKernelGGL((k_blk_bins<T, 2, 2560, false, 2>), g2, dim3(256), 0, st, d->pw, d->pb, d->ps, (const T *)d->prod, d->lrow,
+                               d->rows, d->n_pieces, (T *)y, d->part);
+        else
+            hipLaunchKernelGGL((k_blk_bins<T, 2, 2560, false>), g2, dim3(256), 0, st, d->pw, d->pb, d->ps, (const T *)d->prod, d->lrow,
+                               d->rows, d->n_pieces, (T *)y, d->part);
+        return;
+    }
+#endif
     hipLaunchKernelGGL((k_blk_products<T, 2>), dim3(d->n_wg), dim3(BB_P1_WAVES * 64), 0, st, d->wg, (const T *)d->val1, d->col1,
                        d->dest4, (const T *)x, d->cols, d->wcols, (T *)d->prod);
-    const dim3 g2((d->n_pieces + 3) / 4);
 #define BLK_BINS(RB_)                                                                                                          \
     case RB_:                                                                                                                  \
         if (d->runs)                                                                                                           \

@@ -35,6 +35,9 @@ extern "C" void spmvk_blocked_set_bin_rows(int per_xcd);
 extern "C" void spmvk_hub_set_min_cover(int per_cent);
 extern "C" void spmvk_hub_set_table_bytes(int bytes);
 extern "C" void spmvk_hub_set_lds_cap(int columns);
+#ifdef SPMV_HIP_DEBUG_BUILD
+extern "C" void spmvk_blocked_set_abl(int v);
+#endif
 extern "C" int spmvk_get_tuning_xcd(void);
 static bool g_tune_xcd_enabled() { return spmvk_get_tuning_xcd() != 0; }
 
@@ -1549,6 +1552,8 @@ void spmv_hip_set_tuning(int key, int value)
     else if (key == 15 && value >= 0 && value <= 2)
         g_stripe_shape = value; /* 0: chosen per matrix, 1: 16 waves x 128 KiB, 2: 8 waves x 64 KiB */
 #ifdef SPMV_HIP_DEBUG_BUILD
+    else if (key == 26)
+        spmvk_blocked_set_abl(value); /* BLOCKED: timing-only probes of the byte budget (results are wrong) */
     else if (key == 14)
         g_fail_relayout_alloc = value != 0;
 #endif
