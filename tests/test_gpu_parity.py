@@ -1548,6 +1548,41 @@ m.close(); be.release()
     m.close()
 
 
+def test_auto_takes_hub_for_real_hubs_only(pkg, backend, oracle):
+    """HUB is nominated by size (2 M nonzeros over 1 MB of x, the CSR kernel otherwise) and kept by its builder only when the
+    LDS table's columns take a quarter of the entries AND are referenced four times as often as the average column that is
+    referenced at all.  The first audit of round 4 (profiles/r04_dispatch_audit_before_the_criterion.log) admitted it on the
+    coverage of both table tiers and lost 13-63 % on uniformly scattered and banded columns: those stay on the CSR kernels,
+    a power-law graph of the same size goes to HUB, and both agree with the oracle."""
+    rng = np.random.default_rng(150)
+    rows = 400000
+    rs, ci, a = matgen.npb_like(151, rows, 8)                     # 3.2 M nonzeros, columns uniform over 3.2 MB of x
+    lens = np.diff(rs).astype(np.int64)
+    k = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+    ci_banded = ((np.repeat(np.arange(rows, dtype=np.int64), lens) + 3 * k) % rows + 1).astype(np.int32)
+    ci_few = ((ci.astype(np.int64) - 1) % 60000 * 5 + 1).astype(np.int32)  # 60 000 columns used, uniformly: the table would cover half of them
+    x = rng.standard_normal(rows)
+    for name, cols in (("uniform", ci), ("banded", ci_banded), ("few columns, evenly used", ci_few)):
+        m = backend.matrix(a, rs, cols, rows)
+        try:
+            inf = m.info()
+            assert inf["plan"] in (pkg.PLAN_STREAM, pkg.PLAN_VECTOR, pkg.PLAN_STRIPED), (name, inf)
+            assert_close_rows(m.spmv_host(x), oracle.spmv(a, x, rs, cols, rows),
+                              oracle.absum(a, x, rs, cols, rows), np.diff(rs), np.float64, name)
+        finally:
+            m.close()
+    rs_g, ci_g, a_g = matgen.rmat_graph(152, 18, 16, np.float64, values="normal")  # 3.9 M nonzeros, 2 MB of x
+    n = rs_g.size - 1
+    xg = rng.standard_normal(int(ci_g.max()))
+    m = backend.matrix(a_g, rs_g, ci_g, n)
+    try:
+        assert m.info()["plan"] == pkg.PLAN_HUB, m.info()
+        assert_close_rows(m.spmv_host(xg), oracle.spmv(a_g, xg, rs_g, ci_g, n), oracle.absum(a_g, xg, rs_g, ci_g, n), np.diff(rs_g),
+                          np.float64, "rmat18", HUB)
+    finally:
+        m.close()
+
+
 def test_auto_takes_blocked_for_scattered_columns_only(pkg, backend, oracle):
     """spmv_plan_choose nominates BLOCKED by shape (x of 16 MB and more, rows too short for STRIPED); the builder, which
     counts the entries of every (stripe, bin) cell, takes the nomination back when the columns are local to the rows (the CSR
