@@ -315,7 +315,6 @@ std::atomic<int> g_hub_min_cover{25}; /* per cent of the entries that must hit a
 std::atomic<int> g_hub_table_bytes{SPMV_HUB_TABLE_BYTES}; /* tier 1: bytes of the dense table in memory (0: none) */
 std::atomic<int> g_hub_lds_cap{1 << 30};                  /* tier 0: at most this many columns in the LDS table (tests: small, so
                                                              that small matrices reach tier 1 and x itself) */
-int g_hub_cus = 0;
 
 } // namespace
 
@@ -369,6 +368,7 @@ extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host
     int *d_cnt = nullptr, *h_cnt = nullptr, *d_slot = nullptr, *h_hubcol = nullptr;
     int base1 = 0;
     size_t n_slots = 0;
+    int hub_cus = 256;
     spmv_hub_plan g;
     spmv_dev_hub d;
     memset(&g, 0, sizeof g);
@@ -449,11 +449,10 @@ extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host
         HBCHK(hipMemcpyAsync(d.fix, g.fix, (size_t)g.n_fix * 3 * sizeof(int), hipMemcpyHostToDevice, st));
     HBCHK(hipMalloc(&d.carry, ((size_t)g.n_chunks + 1) * (size_t)elem_size));
     HBCHK(hipStreamSynchronize(st));
-    if (!g_hub_cus) {
+    {   /* one persistent workgroup per CU of the device the layout is built on */
         int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        g_hub_cus = cus;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            hub_cus = cus;
     }
     d.val = d_val;
     d.elem = elem_size, d.rows = rows, d.cols = cols, d.K = g.K, d.K2 = g.K2, d.base1 = base1, d.slots = slots, d.CH = CH;
@@ -462,8 +461,8 @@ extern "C" int spmv_hub_build_device(const int *d_rowptr, const int *rowptr_host
     d.nnz = nnz, d.covered = g.covered;
     {
         int nwg = (g.n_chunks + WAVES - 1) / WAVES; /* a wave should find at least one chunk */
-        if (nwg > g_hub_cus)
-            nwg = g_hub_cus;
+        if (nwg > hub_cus)
+            nwg = hub_cus;
         d.n_wg = nwg < 1 ? 1 : nwg;
     }
     d.bytes = n_alloc * 4 + (n_slots + 1) * 4 + (n_slots + 16) * (size_t)elem_size + ((size_t)g.n_chunks + 1) * (4 + (size_t)elem_size) +
