@@ -28,13 +28,19 @@
  *      pushed to the other N - 1 copies with hipMemcpyPeerAsync on the part's stream (class D over 8 GPUs: 1.5 MB to 7
  *      peers each, point to point over xGMI)
  * Results are a function of the partition (N and the row bounds), reproducible run to run; zeta agrees with the one-GPU
- * run to ~1e-13.  One host thread issues everything (per iteration and part: 8 launches, N - 1 copies, 3 event records
- * and waits through one hub stream): at N = 8 that is ~200 API calls per iteration -- expect the host, not the GPUs, to
- * bound class D at 8 GPUs.  UNMEASURED on more than one GPU: every test runs the parts wrapped onto one device, where
- * the peer copy degenerates to a device-to-device copy.
+ * run to ~1e-13.  Per iteration and part: 9 launches, N - 1 copies, three exchanges -- ~75 us of API calls when ONE host
+ * thread issues for everybody (profiles/r04_cg_parts_host_cost.log), i.e. more than the kernels of a class D row block at
+ * N = 8; so when the parts lie on several devices every part gets a host thread of its own (cgm_thread_main; the threads
+ * meet at a spinning barrier at every exchange).  SPMV_HIP_CG_THREADS = 0 / 1 forces either; the bits are the same.
+ * UNMEASURED on more than one GPU: every test runs the parts wrapped onto one device, where the peer copy degenerates to a
+ * device-to-device copy.
  */
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+#include <sched.h>
+
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -285,6 +291,10 @@ struct spmv_hip_cg {
     cg_part *parts = nullptr;
     double *h_slots = nullptr; /* pinned: [3][np] -- rho generation 0, rho generation 1, d: one double per part */
     hipEvent_t join = nullptr;
+    /* a host thread per part (SPMV_HIP_CG_THREADS = 1 / 0; default: when the parts lie on more than one device) */
+    int threads = 0;
+    hipEvent_t *t_ev[2] = {nullptr, nullptr};
+    std::atomic<int> t_fail{0}, t_go{0}, t_arrived{0}, t_gen{0};
 };
 
 namespace {
@@ -353,6 +363,13 @@ void multi_free(spmv_hip_cg *c)
         (void)hipHostFree(c->h_slots);
     if (c->join)
         (void)hipEventDestroy(c->join);
+    for (int set = 0; set < 2; ++set) {
+        for (int k = 0; c->t_ev[set] && k < c->np; ++k)
+            if (c->t_ev[set][k])
+                (void)hipEventDestroy(c->t_ev[set][k]);
+        delete[] c->t_ev[set];
+        c->t_ev[set] = nullptr;
+    }
 }
 
 #define CGM(expr)                                                                                       \
@@ -364,107 +381,238 @@ void multi_free(spmv_hip_cg *c)
         }                                                                                               \
     } while (0)
 
-/* conj_grad over the row partitions; see the head of this file */
+/* ---- conj_grad over the row partitions, phase by phase (see the head of this file).  A phase is what ONE part enqueues
+ * between two exchanges; the driver below runs the phases of all parts in turn from one thread, or every part's phases from
+ * a thread of its own. */
+struct cgm_ctx {
+    spmv_hip_cg *c;
+    double *h_rho[2], *h_d;
+};
+
+/* r = p = x, z = q = 0, rho (cg.f:492-506); the part's slice of p to every other copy */
+int cgm_phase_init(const cgm_ctx &X, int k, int gen)
+{
+    cg_part &p = X.c->parts[k];
+    CGM(hipSetDevice(p.device));
+    if (p.rows > 0)
+        hipLaunchKernelGGL(k_cg_init, dim3(p.nb), dim3(256), 0, p.stream, p.x, p.z, p.pfull + p.r0, p.q, p.r, p.part[0], p.rows);
+    hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, p.stream, p.part[0], p.nb, X.h_rho[gen] + k);
+    CGM(hipGetLastError());
+    return multi_push_slice(X.c, k, p.pfull + p.r0);
+}
+
+/* 1. q_k = A_k p and d_k = p_k . q_k (cg.f:532, 573-577) */
+int cgm_phase_spmv(const cgm_ctx &X, int k)
+{
+    cg_part &p = X.c->parts[k];
+    CGM(hipSetDevice(p.device));
+    int nd = 0;
+    if (p.rows > 0) {
+        nd = spmvd_spmv_dot(p.m, p.pfull, p.q, p.stream, p.pfull + p.r0, p.part[2]);
+        if (nd < 0)
+            return -1;
+        if (nd == 0) {
+            if (spmv_hip_spmv_device(p.m, p.pfull, p.q, p.stream))
+                return -1;
+            CGM(hipSetDevice(p.device));
+            hipLaunchKernelGGL(k_cg_dot, dim3(p.nb), dim3(256), 0, p.stream, p.pfull + p.r0, p.q, p.part[2], (const double *)nullptr,
+                               (const double *)nullptr, (double *)nullptr, p.rows);
+            nd = p.nb;
+        }
+    }
+    hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, p.stream, p.part[2], nd, X.h_d + k);
+    CGM(hipGetLastError());
+    return 0;
+}
+
+/* 2. alpha = rho / d; z, r; rho' (cg.f:581-605) */
+int cgm_phase_axpy(const cgm_ctx &X, int k, int gen)
+{
+    cg_part &p = X.c->parts[k];
+    CGM(hipSetDevice(p.device));
+    hipLaunchKernelGGL(k_cgm_combine, dim3(1), dim3(64), 0, p.stream, X.h_rho[gen], X.h_d, X.c->np, p.sc);
+    if (p.rows > 0)
+        hipLaunchKernelGGL(k_cgm_axpy, dim3(p.nb), dim3(256), 0, p.stream, p.z, p.r, p.pfull + p.r0, p.q, p.sc, p.part[1], p.rows);
+    hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, p.stream, p.part[1], p.nb, X.h_rho[gen ^ 1] + k);
+    CGM(hipGetLastError());
+    return 0;
+}
+
+/* 3. beta = rho' / rho; p = r + beta p, into every copy of p (cg.f:610-617) */
+int cgm_phase_pupd(const cgm_ctx &X, int k, int gen)
+{
+    cg_part &p = X.c->parts[k];
+    CGM(hipSetDevice(p.device));
+    hipLaunchKernelGGL(k_cgm_combine, dim3(1), dim3(64), 0, p.stream, X.h_rho[gen ^ 1], X.h_rho[gen], X.c->np, p.sc + 2);
+    if (p.rows > 0)
+        hipLaunchKernelGGL(k_cgm_pupd, dim3(p.nb), dim3(256), 0, p.stream, p.pfull + p.r0, p.r, p.sc + 2, p.rows);
+    CGM(hipGetLastError());
+    return multi_push_slice(X.c, k, p.pfull + p.r0);
+}
+
+/* r = A z (cg.f:628), first half: z gathered into every part's full vector (p is dead until the next call's init) */
+int cgm_phase_gather_z(const cgm_ctx &X, int k)
+{
+    cg_part &p = X.c->parts[k];
+    CGM(hipSetDevice(p.device));
+    if (p.rows > 0)
+        CGM(hipMemcpyAsync(p.pfull + p.r0, p.z, (size_t)p.rows * sizeof(double), hipMemcpyDeviceToDevice, p.stream));
+    return multi_push_slice(X.c, k, p.z);
+}
+
+/* ... second half: the product, the partials of ||x - r||^2 to the host; the part's stream is drained */
+int cgm_phase_resid(const cgm_ctx &X, int k)
+{
+    cg_part &p = X.c->parts[k];
+    CGM(hipSetDevice(p.device));
+    if (p.rows > 0) {
+        if (spmv_hip_spmv_device(p.m, p.pfull, p.r, p.stream))
+            return -1;
+        CGM(hipSetDevice(p.device));
+        hipLaunchKernelGGL(k_cg_resid, dim3(p.nb), dim3(256), 0, p.stream, p.x, p.r, p.part[3], p.rows);
+        CGM(hipGetLastError());
+        CGM(hipMemcpyAsync(X.c->h_part + p.r0 / VB + k, p.part[3], (size_t)p.nb * sizeof(double), hipMemcpyDeviceToHost, p.stream));
+    }
+    CGM(hipStreamSynchronize(p.stream));
+    return 0;
+}
+
+/* ---- a thread per part: every part's launches, copies and waits are issued by its own host thread (one thread issuing for
+ * eight GPUs is ~200 API calls per CG iteration: more than the kernels take).  The exchange points are the same; at each
+ * the thread records its event, meets the others at a host barrier -- so that every record has happened --, then lets its
+ * stream wait for the other parts' events.  Two sets of events alternate: a set is recorded again only two exchanges later,
+ * when every thread is long past the waits that captured its previous record. */
+struct cgm_thread {
+    cgm_ctx X;
+    int k, cgitmax, rc;
+    pthread_t th;
+};
+
+int cgm_thread_exchange(const cgm_ctx &X, int k, int &set, int rc_so_far)
+{
+    spmv_hip_cg *c = X.c;
+    cg_part &p = c->parts[k];
+    if (rc_so_far)
+        c->t_fail.store(1, std::memory_order_relaxed);
+    if (hipSetDevice(p.device) != hipSuccess || hipEventRecord(c->t_ev[set][k], p.stream) != hipSuccess)
+        c->t_fail.store(1, std::memory_order_relaxed);
+    /* every thread comes here, failed or not: nobody is left waiting.  A spinning barrier (generation counter): the threads meet
+     * three times per CG iteration, a futex sleep and wake-up each time would cost more than the launches between them */
+    {
+        const int gen0 = c->t_gen.load(std::memory_order_acquire);
+        if (c->t_arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->np) {
+            c->t_arrived.store(0, std::memory_order_relaxed);
+            c->t_gen.store(gen0 + 1, std::memory_order_release);
+        } else {
+            for (unsigned spins = 0; c->t_gen.load(std::memory_order_acquire) == gen0; ++spins)
+                if (spins > 20000)
+                    sched_yield(); /* more threads than cores: let the others run */
+        }
+    }
+    if (c->t_fail.load(std::memory_order_relaxed))
+        return -1;
+    for (int j = 0; j < c->np; ++j)
+        if (j != k && hipStreamWaitEvent(p.stream, c->t_ev[set][j], 0) != hipSuccess) {
+            spmv_set_error("hipStreamWaitEvent failed between row partitions %d and %d", k, j);
+            c->t_fail.store(1, std::memory_order_relaxed); /* seen by everybody at the next exchange */
+        }
+    set ^= 1;
+    return 0;
+}
+
+void *cgm_thread_main(void *arg)
+{
+    cgm_thread *T = (cgm_thread *)arg;
+    const cgm_ctx &X = T->X;
+    const int k = T->k;
+    int set = 0, gen = 0;
+    /* nobody enqueues anything before every thread exists (a thread that could not be created would leave the others at the
+     * first exchange for ever): t_go 1 = all there, -1 = give up */
+    for (int go = 0; (go = X.c->t_go.load(std::memory_order_acquire)) != 1;) {
+        if (go < 0) {
+            T->rc = -2;
+            return nullptr;
+        }
+        sched_yield();
+    }
+    /* the number of exchanges is the same in every thread whatever happens: a failed phase only raises the flag */
+#define CGM_STEP(call)                                  \
+    if (cgm_thread_exchange(X, k, set, (call)) != 0) {  \
+        T->rc = -1;                                     \
+        return nullptr;                                 \
+    }
+    CGM_STEP(cgm_phase_init(X, k, gen));
+    for (int it = 0; it < T->cgitmax; ++it) {
+        CGM_STEP(cgm_phase_spmv(X, k));
+        CGM_STEP(cgm_phase_axpy(X, k, gen));
+        CGM_STEP(cgm_phase_pupd(X, k, gen));
+        gen ^= 1;
+    }
+    CGM_STEP(cgm_phase_gather_z(X, k));
+    CGM_STEP(cgm_phase_resid(X, k)); /* drains the stream; the exchange behind it: nobody starts the next call's init early */
+#undef CGM_STEP
+    T->rc = 0;
+    return nullptr;
+}
+
 int multi_conj_grad(spmv_hip_cg *c, int cgitmax, double *rnorm)
 {
     cg_part *P = c->parts;
     const int np = c->np;
-    double *h_rho[2] = {c->h_slots, c->h_slots + np}, *h_d = c->h_slots + 2 * np;
-    int gen = 0; /* h_rho[gen]: rho of the current residual */
-    /* r = p = x, z = q = 0, rho (cg.f:492-506); every copy of p complete before the first product */
-    for (int k = 0; k < np; ++k) {
-        CGM(hipSetDevice(P[k].device));
-        if (P[k].rows > 0)
-            hipLaunchKernelGGL(k_cg_init, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].x, P[k].z, P[k].pfull + P[k].r0, P[k].q,
-                               P[k].r, P[k].part[0], P[k].rows);
-        hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, P[k].stream, P[k].part[0], P[k].nb, h_rho[gen] + k);
-        CGM(hipGetLastError());
-        if (multi_push_slice(c, k, P[k].pfull + P[k].r0))
+    cgm_ctx X;
+    X.c = c;
+    X.h_rho[0] = c->h_slots, X.h_rho[1] = c->h_slots + np, X.h_d = c->h_slots + 2 * np;
+    if (c->threads && np > 1) {
+        cgm_thread *T = new cgm_thread[np];
+        c->t_fail.store(0, std::memory_order_relaxed);
+        c->t_arrived.store(0, std::memory_order_relaxed);
+        c->t_go.store(0, std::memory_order_release);
+        int started = 1; /* part 0 runs on the calling thread */
+        for (int k = 0; k < np; ++k)
+            T[k].X = X, T[k].k = k, T[k].cgitmax = cgitmax, T[k].rc = -1;
+        for (int k = 1; k < np; ++k) {
+            if (pthread_create(&T[k].th, nullptr, cgm_thread_main, &T[k]) != 0)
+                break;
+            ++started;
+        }
+        c->t_go.store(started == np ? 1 : -1, std::memory_order_release);
+        if (started == np)
+            cgm_thread_main(&T[0]);
+        for (int k = 1; k < started; ++k)
+            pthread_join(T[k].th, nullptr);
+        int rc = started == np ? 0 : -1;
+        if (started != np)
+            spmv_set_error("spmv_hip_cg: could not start the %d host threads of the row partitions (SPMV_HIP_CG_THREADS=0 runs them from one)", np - 1);
+        for (int k = 0; k < np && started == np; ++k)
+            rc |= T[k].rc;
+        delete[] T;
+        if (rc)
             return -1;
-    }
-    if (multi_barrier(c))
+    } else {
+        int gen = 0; /* h_rho[gen]: rho of the current residual */
+#define CGM_ALL(call)               \
+    for (int k = 0; k < np; ++k)    \
+        if ((call) != 0)            \
+            return -1;              \
+    if (multi_barrier(c))           \
         return -1;
-    for (int it = 0; it < cgitmax; ++it) {
-        /* 1. q_k = A_k p and d_k = p_k . q_k (cg.f:532, 573-577) */
-        for (int k = 0; k < np; ++k) {
-            CGM(hipSetDevice(P[k].device));
-            int nd = 0;
-            if (P[k].rows > 0) {
-                nd = spmvd_spmv_dot(P[k].m, P[k].pfull, P[k].q, P[k].stream, P[k].pfull + P[k].r0, P[k].part[2]);
-                if (nd < 0)
-                    return -1;
-                if (nd == 0) {
-                    if (spmv_hip_spmv_device(P[k].m, P[k].pfull, P[k].q, P[k].stream))
-                        return -1;
-                    CGM(hipSetDevice(P[k].device));
-                    hipLaunchKernelGGL(k_cg_dot, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].pfull + P[k].r0, P[k].q, P[k].part[2],
-                                       (const double *)nullptr, (const double *)nullptr, (double *)nullptr, P[k].rows);
-                    nd = P[k].nb;
-                }
-            }
-            hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, P[k].stream, P[k].part[2], nd, h_d + k);
-            CGM(hipGetLastError());
+        CGM_ALL(cgm_phase_init(X, k, gen));
+        for (int it = 0; it < cgitmax; ++it) {
+            CGM_ALL(cgm_phase_spmv(X, k));
+            CGM_ALL(cgm_phase_axpy(X, k, gen));
+            CGM_ALL(cgm_phase_pupd(X, k, gen));
+            gen ^= 1;
         }
-        if (multi_barrier(c))
-            return -1;
-        /* 2. alpha = rho / d; z, r; rho' (cg.f:581-605) */
-        for (int k = 0; k < np; ++k) {
-            CGM(hipSetDevice(P[k].device));
-            hipLaunchKernelGGL(k_cgm_combine, dim3(1), dim3(64), 0, P[k].stream, h_rho[gen], h_d, np, P[k].sc);
-            if (P[k].rows > 0)
-                hipLaunchKernelGGL(k_cgm_axpy, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].z, P[k].r, P[k].pfull + P[k].r0, P[k].q,
-                                   P[k].sc, P[k].part[1], P[k].rows);
-            hipLaunchKernelGGL(k_cgm_scalar, dim3(1), dim3(64), 0, P[k].stream, P[k].part[1], P[k].nb, h_rho[gen ^ 1] + k);
-            CGM(hipGetLastError());
-        }
-        if (multi_barrier(c))
-            return -1;
-        /* 3. beta = rho' / rho; p = r + beta p, into every copy of p (cg.f:610-617) */
-        for (int k = 0; k < np; ++k) {
-            CGM(hipSetDevice(P[k].device));
-            hipLaunchKernelGGL(k_cgm_combine, dim3(1), dim3(64), 0, P[k].stream, h_rho[gen ^ 1], h_rho[gen], np, P[k].sc + 2);
-            if (P[k].rows > 0)
-                hipLaunchKernelGGL(k_cgm_pupd, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].pfull + P[k].r0, P[k].r, P[k].sc + 2,
-                                   P[k].rows);
-            CGM(hipGetLastError());
-            if (multi_push_slice(c, k, P[k].pfull + P[k].r0))
-                return -1;
-        }
-        if (multi_barrier(c))
-            return -1;
-        gen ^= 1;
+        CGM_ALL(cgm_phase_gather_z(X, k));
+        CGM_ALL(cgm_phase_resid(X, k));
+#undef CGM_ALL
     }
-    /* r = A z (cg.f:628): z gathered into every part's full vector (p is dead until the next call's init), then ||x - r|| */
-    for (int k = 0; k < np; ++k) {
-        CGM(hipSetDevice(P[k].device));
-        if (P[k].rows > 0)
-            CGM(hipMemcpyAsync(P[k].pfull + P[k].r0, P[k].z, (size_t)P[k].rows * sizeof(double), hipMemcpyDeviceToDevice, P[k].stream));
-        if (multi_push_slice(c, k, P[k].z))
-            return -1;
-    }
-    if (multi_barrier(c))
-        return -1;
     double s = 0.0;
     for (int k = 0; k < np; ++k) {
-        if (P[k].rows == 0)
-            continue;
-        if (spmv_hip_spmv_device(P[k].m, P[k].pfull, P[k].r, P[k].stream))
-            return -1;
-        CGM(hipSetDevice(P[k].device));
-        hipLaunchKernelGGL(k_cg_resid, dim3(P[k].nb), dim3(256), 0, P[k].stream, P[k].x, P[k].r, P[k].part[3], P[k].rows);
-        CGM(hipGetLastError());
-        CGM(hipMemcpyAsync(c->h_part + P[k].r0 / VB + k, P[k].part[3], (size_t)P[k].nb * sizeof(double), hipMemcpyDeviceToHost, P[k].stream));
-    }
-    for (int k = 0; k < np; ++k) {
-        CGM(hipSetDevice(P[k].device));
-        CGM(hipStreamSynchronize(P[k].stream));
         const double *hp = c->h_part + P[k].r0 / VB + k; /* part k's partials: at most rows_k / VB + 1 of them */
         for (int i = 0; i < (P[k].rows > 0 ? P[k].nb : 0); ++i)
             s += hp[i];
     }
-    /* a barrier again: nobody starts the next call's init (which rewrites p) while a neighbour still multiplies */
-    if (multi_barrier(c))
-        return -1;
     if (rnorm)
         *rnorm = sqrt(s);
     return 0;
@@ -617,6 +765,23 @@ spmv_hip_cg *spmv_hip_cg_create_multi(spmv_hip_matrix **parts, int nparts)
         ok = ok && hipHostMalloc((void **)&c->h_part, (size_t)(2 * (c->nb + nparts) + 2) * sizeof(double), hipHostMallocDefault) == hipSuccess;
         if (!ok)
             spmv_set_error("spmv_hip_cg_create_multi: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (ok) { /* who issues the work: one thread for all parts, or a thread per part (their events: two sets, see cgm_thread_exchange) */
+        const char *e = getenv("SPMV_HIP_CG_THREADS");
+        bool several_devices = false; /* threads pay when the parts' devices work side by side; parts wrapped onto one GPU share it anyway */
+        for (int k = 1; k < nparts; ++k)
+            several_devices = several_devices || c->parts[k].device != c->parts[0].device;
+        c->threads = e && *e ? atoi(e) != 0 : several_devices;
+        if (c->threads && nparts > 1) {
+            for (int set = 0; set < 2 && ok; ++set) {
+                c->t_ev[set] = new hipEvent_t[nparts]();
+                for (int k = 0; k < nparts && ok; ++k)
+                    ok = hipSetDevice(c->parts[k].device) == hipSuccess &&
+                         hipEventCreateWithFlags(&c->t_ev[set][k], hipEventDisableTiming) == hipSuccess;
+            }
+            if (!ok)
+                spmv_set_error("spmv_hip_cg_create_multi: could not set up the per-part threads' events");
+        }
     }
     if (!ok) {
         spmv_hip_cg_destroy(c);

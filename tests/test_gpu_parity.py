@@ -444,6 +444,19 @@ def test_device_resident_cg_over_row_partitions(pkg, backend, cls, parts):
     assert np.all(r1 <= 10.0 * r0 + 1e-12)  # ||x - A z|| after 25 iterations is rounding noise (1e-13 .. 1e-15) either way
     again = m.run_cg_device_parts(backend, parts)
     assert np.array_equal(np.array(again["zeta_hist"]).view(np.uint64), np.array(res["zeta_hist"]).view(np.uint64))
+    # who issues the work -- one host thread for all parts, or a thread per part (the default when the parts lie on several GPUs) -- changes nothing:
+    # the exchanges and the order of every addition are the same
+    old = os.environ.get("SPMV_HIP_CG_THREADS")
+    try:
+        for mode in ("0", "1"):
+            os.environ["SPMV_HIP_CG_THREADS"] = mode
+            other = m.run_cg_device_parts(backend, parts)
+            assert np.array_equal(np.array(other["zeta_hist"]).view(np.uint64), np.array(res["zeta_hist"]).view(np.uint64)), mode
+    finally:
+        if old is None:
+            os.environ.pop("SPMV_HIP_CG_THREADS", None)
+        else:
+            os.environ["SPMV_HIP_CG_THREADS"] = old
 
 
 def test_device_resident_cg_parts_refuse_what_is_not_a_partition(pkg, backend):
