@@ -1710,6 +1710,44 @@ def test_blocked_through_the_abi_whole_and_in_row_partitions(parts):
     assert int(out[i + 4]) == 1 and int(out[i + 5]) == 1, out
 
 
+HUB_PARTS_SCRIPT = """
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np, pkgload, rowtol, matgen
+from oracle.oracle import Oracle
+p = pkgload.load_package(); be = p.Backend(); o = Oracle()
+rs, ci, a = matgen.rmat_graph(31, 19, 16, np.float64, values="normal")   # 8 M nonzeros, 4 MB of x: hub rows of 25 000 entries
+rows = rs.size - 1
+x = np.random.default_rng(9).standard_normal(int(ci.max()))
+y = np.full(rows, np.nan)
+for _ in range(4):
+    be.harness(y, a, x, rs, ci, rows)
+ref = o.spmv(a, x, rs, ci, rows); ab = o.absum(a, x, rs, ci, rows)
+ok = bool(np.all(np.abs(y - ref) <= rowtol.row_tolerance(np.diff(rs), ab, 2.0 ** -53, rowtol.HUB)))
+y1 = y.copy()
+be.harness(y, a, x, rs, ci, rows)
+same = bool(np.array_equal(y.view(np.uint64), y1.view(np.uint64)))
+a[::7] *= 1.5  # the values change, the structure stays: HUB reads the CSR copy's values, a refresh costs it nothing
+be.harness(y, a, x, rs, ci, rows)
+ref = o.spmv(a, x, rs, ci, rows); ab = o.absum(a, x, rs, ci, rows)
+ok2 = bool(np.all(np.abs(y - ref) <= rowtol.row_tolerance(np.diff(rs), ab, 2.0 ** -53, rowtol.HUB)))
+s = be.stats()
+print("HUBPARTS", int(ok), int(same), int(ok2), p.abi.PLAN_NAMES[be.abi_matrix_info()["plan"]], s["uploads"], s["value_refreshes"])
+"""
+
+
+@pytest.mark.parametrize("parts", ["1", "3"])
+def test_hub_through_the_abi_whole_and_in_row_partitions(parts):
+    """An R-MAT graph through spmv_harness_ in a fresh process: the automatic choice gives HUB to the whole matrix and to each of
+    three row partitions (every part its own tables and chunk lists from its own row pointers; x whole on every part), results
+    within HUB's bar, a repetition bit for bit, and an edit of a[] alone is answered by a value refresh."""
+    out = _run_py(HUB_PARTS_SCRIPT % dict(root=ROOT, tests=os.path.dirname(__file__)),
+                  {"SPMV_HIP_PARTS": parts, "SPMV_HIP_DISPATCH": "device"}).split()
+    i = out.index("HUBPARTS")
+    assert out[i + 1:i + 5] == ["1", "1", "1", "hub"], out
+    assert int(out[i + 5]) == 1 and int(out[i + 6]) == 1, out
+
+
 def test_relayouts_give_their_memory_back(pkg, backend):
     """Every re-laid-out plan allocates a second copy (and scratch) on the device; creating, refreshing and closing such
     matrices over and over must leave the device's free memory where it was (hipMemGetInfo)."""
