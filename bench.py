@@ -27,6 +27,9 @@ and y already resident in HBM.
           (the call pattern of NPB3.3.1/CG/cg.f:532,628), MOp/s by cg.f:395-402, verified against
           cg.f:122-163.
 
+roofline.traffic is measured by the run (N = 1): two child processes of this script behind `rocprofv3 --pmc FETCH_SIZE` /
+`--pmc WRITE_SIZE` (`--no-traffic` quotes the stored figure of profiles/traffic.json instead).
+
 value = 2 * nnz * K / elapsed  (effective GFLOP/s, whole job).  The same K launches are
 bracketed by HIP events recorded on the stream the kernels run on (spmv_hip_time_device), which
 gives the per-launch duration for the roofline object.  Rank 0 at N = 1 additionally reports
@@ -92,6 +95,81 @@ def check_rows(np, m_a, m_rowstr, m_colidx, x, yv, what):
         scale[nz] = np.add.reduceat(np.abs(prod), starts[nz])
     badrows = np.nonzero(~(np.abs(yv - want) <= tolerance(np, lens, scale) + 1e-300))[0]
     assert badrows.size == 0, "%s: %d rows differ, first %d: %r vs %r" % (what, badrows.size, badrows[0], yv[badrows[0]], want[badrows[0]])
+
+
+PRODUCT_KERNELS = ("k_striped", "k_group_sum", "k_stream", "k_long", "k_long_finish", "k_vector", "k_tiled", "k_ordered",
+                   "k_blk_products", "k_blk_bins", "k_blk_join", "k_hub", "k_hub_pack", "k_hub_fix")
+
+
+def traffic_child(args):
+    """`bench.py --traffic-child`: the headline matrix, device-resident, 3 + 10 products and nothing else -- the program the
+    parent puts behind `rocprofv3 --pmc <counter> --kernel-trace --` (one counter per pass, as the guide prescribes)."""
+    import numpy as np
+    import pkgload
+    pkg = pkgload.load_package()
+    be = pkg.Backend()
+    m = pkg.npb.NpbMatrix(args.cls or "C")
+    dm = be.matrix(m.a, m.rowstr, m.colidx, m.rows, device=0, cols_hint=m.na)
+    x = np.random.default_rng(12345).standard_normal(m.na + 2)
+    dx, dy = be.malloc(x.nbytes, 0), be.malloc(max(m.rows, 1) * 8, 0)
+    be.h2d(dx, x, 0)
+    dm.time_device(dx, dy, 3)
+    dm.time_device(dx, dy, TRAFFIC_LAUNCHES)
+    dm.close()
+    be.free(dx, 0), be.free(dy, 0)
+    be.release()  # before the interpreter exits: the profiler shuts down first otherwise
+
+
+TRAFFIC_LAUNCHES = 10
+
+
+def measure_traffic(cls, launches_per_step):
+    """HBM-side bytes per SpMV of the headline workload, measured by THIS run: two child processes of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only; /opt/skills/guides/MI355X_MICROARCH.md,
+    HBM section: FETCH_SIZE counts KB and sees half of a wide coalesced read on gfx950 -> x 2; WRITE_SIZE is exact), the last
+    TRAFFIC_LAUNCHES products of each.  Returns (bytes with the guide's x 2, detail) or (None, why)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "no rocprofv3 on PATH"
+    if any("rocprof" in v.lower() for k, v in os.environ.items() if k in ("LD_PRELOAD", "HSA_TOOLS_LIB")) or \
+            any("ROCPROF" in k or k.startswith("ROCP_") for k in os.environ):
+        return None, "this process runs under a profiler itself"
+    pat = re.compile(r"\b(" + "|".join(PRODUCT_KERNELS) + r")\b")
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-child", "--cls", cls]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "%s pass failed (rc %d): %s" % (counter, r.returncode, r.stdout[-300:])
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter and pat.search(row["Kernel_Name"]):
+                    per[int(row["Dispatch_Id"])] = per.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"]) * 1024.0
+            ids = sorted(per)[-TRAFFIC_LAUNCHES * launches_per_step:]
+            if len(ids) < TRAFFIC_LAUNCHES * launches_per_step:
+                return None, "%s pass: %d product dispatches found, %d expected" % (counter, len(ids), TRAFFIC_LAUNCHES * launches_per_step)
+            got[counter] = sum(per[i] for i in ids) / TRAFFIC_LAUNCHES
+        except Exception as e:  # a measurement aid must not take the bench line down
+            return None, "%s pass: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]), {
+        "kind": "measured by this run", "how": "two child processes of bench.py (--traffic-child) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                "--kernel-trace, the last %d products of each; traffic = 2 x FETCH_SIZE + WRITE_SIZE per product (the guide's gfx950 correction for "
+                "wide reads)" % TRAFFIC_LAUNCHES,
+        "fetch_size_bytes_as_counted": int(got["FETCH_SIZE"]), "write_size_bytes": int(got["WRITE_SIZE"]),
+        "with_round_1_calibration_x2.12": int(2.12 * got["FETCH_SIZE"] + got["WRITE_SIZE"])}
 
 
 def npb_cg_object(m, be, res, st, runs, cls, path):
@@ -265,10 +343,15 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the sparsebench / graphs / parboil objects (N = 1)")
     ap.add_argument("--cpu-iters", type=int, default=10, help="timed CG iterations of the CPU sample")
     ap.add_argument("--no-scale-ref", action="store_true", help="skip the class D single-GPU reference point at N=1")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic (two rocprofv3 --pmc child runs, ~30 s); "
+                    "the stored figure of profiles/traffic.json is quoted instead")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--scale-ref-cls", default=None, help="class of the scale_ref object (default: D, the N > 1 workload, when the "
                     "headline is class C; naming a class runs it whatever the headline's class -- the tests use B)")
     ap.add_argument("--npb-repeats", type=int, default=5, help="runs of the full NPB CG benchmark at N=1; the median is reported")
     args = ap.parse_args()
+    if args.traffic_child:
+        return traffic_child(args)
 
     import numpy as np
     import torch
@@ -499,7 +582,15 @@ def main():
                                "guide_correction": 2.0}
         except Exception:
             traffic = None
-
+    if rank == 0 and n_gpus == 1 and not args.no_traffic and args.plan == "auto":
+        live, detail = measure_traffic(cls, info["n_launches"])
+        if live is not None:
+            if traffic_src is not None:
+                detail["stored_figure_for_comparison"] = {"hbm_bytes_per_launch": traffic, "file": traffic_src.get("file"),
+                                                          "fetch_correction": traffic_src.get("fetch_correction")}
+            traffic, traffic_src = live, detail
+        elif traffic_src is not None:
+            traffic_src["not_measured_because"] = detail
     na_total = m_na
     line = {
         "metric": "NPB CG class %s SpMV effective GFLOP/s (FP64 CSR y=A*x, HBM-resident; %% of HBM roofline "

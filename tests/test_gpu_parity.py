@@ -1241,6 +1241,10 @@ def test_bench_line_has_the_contract_keys():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-3
+    # roofline.traffic is measured by the run itself (two rocprofv3 --pmc child passes) and lies near the algorithmic bytes
+    ts = d["roofline"]["traffic_source"]
+    assert ts["kind"] == "measured by this run", ts
+    assert 0.4 * d["roofline"]["algorithmic_bytes_per_launch"] < d["roofline"]["traffic"] < 1.6 * d["roofline"]["algorithmic_bytes_per_launch"], d["roofline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["cores"] == 1
     assert d["npb_cg"]["verified"] and d["npb_cg_device"]["verified"]
     assert set(("launch_us", "launches", "frac")) <= set(d["cold"]) and d["cold"]["launches"] == 20
@@ -1262,7 +1266,7 @@ def test_bench_line_attributes_the_graph_callers_time():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k != "SPMV_HIP_DISPATCH"}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cls", "A", "--steps", "5", "--warmup", "1", "--no-cpu", "--no-npb",
-                        "--no-scale-ref", "--prewarm", "24"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=root, env=env)
+                        "--no-scale-ref", "--prewarm", "24", "--no-traffic"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     g = d["graphs_rmat20"]
