@@ -10,6 +10,8 @@ from hypothesis import strategies as st
 import matgen
 from test_plan import striped_emulate, tiled_emulate
 import test_blocked_layout as blk
+import hub_order
+from rowtol import HUB, row_tolerance
 
 
 @pytest.fixture(scope="module")
@@ -109,3 +111,43 @@ def test_blocked_plan_on_any_shape(lib, shape, bin_rows):
     y_ref, ab = reference(rs, ci, a, x)
     tol = (np.diff(rs) + 12) * 2.0 ** -53 * ab
     assert np.all(np.abs(y - y_ref) <= tol + 1e-300)
+
+
+@settings(**COMMON)
+@given(csr_shapes(), st.sampled_from([0, 1, 5, 64, 16352]), st.sampled_from([0, 3, 4000]), st.sampled_from([np.float64, np.float32]))
+def test_hub_plan_on_any_shape(lib, shape, kmax, kmax2, dtype):
+    """csrc/spmv_hub_plan.c + tests/hub_order.py: for any shape, any sizes of the two table tiers and both precisions the plan keeps
+    its invariants -- hub slots a bijection onto the chosen columns, the tiers disjoint, chunk ranks monotone and ending at
+    the number of rows that have entries, every row that crosses a chunk boundary listed once with its chunks -- and the
+    product restated in the kernel's own order of additions reproduces y = A x within HUB's derived bar."""
+    rs, ci, a, seed = shape
+    if ci.size == 0:
+        return
+    a = a.astype(dtype)
+    cols = int(ci.max())
+    p = hub_order.plan(lib, rs, ci, cols, kmax, kmax2=kmax2)
+    cnt = np.bincount(ci - 1, minlength=cols)
+    K, K2 = p["K"], p["K2"]
+    assert K <= kmax and K2 <= kmax2 and not np.intersect1d(p["hubcol"], p["hubcol2"]).size
+    assert np.array_equal(p["slot_of"][p["hubcol"]], np.arange(K)) and np.array_equal(p["slot_of"][p["hubcol2"]], K + np.arange(K2))
+    assert int(np.count_nonzero(p["slot_of"] >= 0)) == K + K2
+    assert p["covered"] == int(cnt[p["hubcol"]].sum()) and p["covered2"] == int(cnt[p["hubcol2"]].sum())
+    lens = np.diff(rs)
+    assert np.all(np.diff(p["rank0"]) >= 0) and p["rank0"][-1] == int(np.count_nonzero(lens)) == p["nzrow"].size
+    assert np.array_equal(np.sort(np.concatenate([p["nzrow"], p["erow"]])), np.arange(rs.size - 1))
+    assert np.all(p["fix"][:, 1] < p["fix"][:, 2]) and np.unique(p["fix"][:, 0]).size == p["fix"].shape[0]
+    x = np.random.default_rng(seed + 7).standard_normal(cols).astype(dtype)
+    y = hub_order.product(p, rs, ci, a, x)
+    a64, x64 = a.astype(np.float64), x.astype(np.float64)
+    y_ref = np.zeros(rs.size - 1)
+    ab = np.zeros(rs.size - 1)
+    for r in range(rs.size - 1):  # the reference's order, in the matrix's own precision
+        lo, hi = rs[r] - 1, rs[r + 1] - 1
+        acc = dtype(0)
+        for j in range(lo, hi):
+            acc = dtype(acc + dtype(a[j] * x[ci[j] - 1]))
+        y_ref[r] = acc
+        ab[r] = np.abs(a64[lo:hi] * x64[ci[lo:hi] - 1]).sum()
+    tol = row_tolerance(lens, ab, 2.0 ** -53 if dtype == np.float64 else 2.0 ** -24, HUB)
+    assert np.all(np.abs(y.astype(np.float64) - y_ref) <= tol + 1e-300)
+    assert np.all(y[lens == 0] == 0)
