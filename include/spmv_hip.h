@@ -195,7 +195,9 @@ int spmv_hip_synchronize(int device);
  * 128 KiB of x, 2 = 8 waves x 64 KiB); 17 who converts to STRIPED (0 = the GPU, from the CSR copy in HBM, the host threads
  * when it must; 1 = the host; 2 = the GPU or fail); 18 BLOCKED: rows per bin of layouts built from now on (0 = sized to fill whole rounds of phase 2; 1024 ... 2560 in steps of 256); 19 STRIPED: per mille of weight
  * moved from the workgroups of even XCDs to those of odd ones (default 0: measured, within noise); 20 STRIPED: the packed
- * stream is loaded non-temporally 0 = when it exceeds the Infinity Cache, 1 = always, 2 = never.  Diagnostics (ablation bits, clock stamps, fault injection) are not in this
+ * stream is loaded non-temporally 0 = when it exceeds the Infinity Cache, 1 = always, 2 = never; 21-23 HUB layouts built from
+ * now on: per cent of the entries that the LDS table's columns must take for the automatic choice to keep the plan (default 25),
+ * bytes of the dense second-tier table in memory (default 2 MB, 0 = none), most columns in the LDS table (< 0: what fits).  Diagnostics (ablation bits, clock stamps, fault injection) are not in this
  * library: they live in the debug build, include/spmv_hip_debug.h. */
 void spmv_hip_set_tuning(int key, int value);
 
