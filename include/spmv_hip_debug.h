@@ -16,10 +16,10 @@ extern "C" {
 
 /*
  * Additional spmv_hip_set_tuning keys of the debug build:
- *    5  register sets of k_striped as well (2, 3, 4; default 2; 3 and 4 run the instrumented twin)
+ *    5  register sets of k_striped as well (2, 3, 4; default 2; 3 and 4 run the instrumented twin);
+ *       12 / 13 / 14: clean instantiations with 2 sets x 4 accumulators / 3 x 8 / 4 x 4 for layouts with short wave ranges
  *    6  k_striped ablation / diagnostic bits, timing experiments only -- RESULTS ARE WRONG when set:
- *       4 no accumulator updates, 8 no ring writes, 16 no segmented scan, 64 clock stamps, 128 no priority rotation
- *        12 / 13 / 14: clean instantiations with 2 sets x 4 accumulators / 3 x 8 / 4 x 4 for layouts with short wave ranges
+ *       4 no accumulator updates, 8 no ring writes, 16 no segmented scan, 64 clock stamps, 128 no priority rotation,
  *       32 loads + LDS gathers + four adds per lane only (what a one-row-per-lane layout would leave)
  *   14  the next re-layout upload fails as if the device were out of memory (consumed by one upload)
  *   26  BLOCKED byte-budget probes, timing only: 1 phase 1 without its destination stream, 2 phase 2 without its row stream
